@@ -1,0 +1,88 @@
+/* ss2d.h -- C ABI of libss2d_hip.so: the MI355X (gfx950) implementation of Mamba-UNet's SS2D hot path.
+ *
+ * Boundary being replaced (the reference has no FFI layer; its operator boundary is Python):
+ *   - `selective_scan_fn` of the third-party CUDA package mamba_ssm, imported at
+ *     /root/reference/code/networks/mamba_sys.py:17-20 and called at :436-442
+ *     (semantics text embedded at :62-144);
+ *   - the chain of torch ops of SS2D.forward_corev0 / SS2D.forward, mamba_sys.py:396-461, :552-565.
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library never allocates or frees
+ *     device memory and never synchronises; all work is enqueued on `stream` (a hipStream_t);
+ *   - tensors are contiguous, row-major, fp32 unless `dtype` says otherwise;
+ *   - return 0 on success; <0 = rejected argument (see ss2d_last_error()); >0 = hipError_t;
+ *   - no C++ exception crosses the boundary; the only global state is a thread-local error string.
+ */
+#ifndef SS2D_H
+#define SS2D_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS2D_ABI_VERSION 1
+#define SS2D_DTYPE_F32 0
+#define SS2D_DTYPE_BF16 1   /* u, delta, B, C, z, out and their grads in bf16; params and state fp32 */
+#define SS2D_SCAN_CHUNK 128 /* positions per state checkpoint */
+#define SS2D_MAX_DSTATE 16
+
+int ss2d_abi_version(void);
+const char *ss2d_last_error(void);
+
+/* Number of state checkpoints per (batch, channel) row that the forward writes for the backward:
+ * ceil(L / SS2D_SCAN_CHUNK).  Checkpoint buffer = batch*dim*chunks*dstate floats. */
+int ss2d_scan_num_chunks(int L);
+size_t ss2d_scan_ckpt_bytes(int batch, int dim, int L, int dstate);
+
+/* selective_scan_fn forward -- replaces mamba_ssm.selective_scan_fn as called at mamba_sys.py:436-442.
+ *   u, delta, z, out : (batch, dim, L)      A : (dim, dstate) fp32, real
+ *   B, C             : (batch, ngroups, dstate, L), dim % ngroups == 0, group(d) = d / (dim/ngroups)
+ *   D, delta_bias    : (dim) fp32, nullable        z : nullable (out *= silu(z))
+ *   last_state       : (batch, dim, dstate) fp32, nullable
+ *   ckpt             : nullable; state entering every SS2D_SCAN_CHUNK-long chunk, (batch, dim, chunks, dstate)
+ *   delta_softplus   : delta <- softplus(delta + delta_bias) (torch threshold 20), as at mamba_sys.py:68-69 */
+int ss2d_selective_scan_fwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                            const void *C, const float *D, const void *z, const float *delta_bias, void *out,
+                            float *last_state, float *ckpt, int batch, int dim, int L, int dstate, int ngroups,
+                            int delta_softplus, void *stream);
+
+/* selective_scan_fn backward (the autograd half of the same boundary).
+ *   du, ddelta, dz : (batch, dim, L)   dB, dC : (batch, ngroups, dstate, L) fp32 ALWAYS
+ *   dA : (dim, dstate)   dD, ddelta_bias : (dim)     (dD / dz / ddelta_bias nullable with D / z / delta_bias)
+ *   dA, dD, ddelta_bias, dB, dC are ACCUMULATED INTO with float atomics: the caller zero-fills them.
+ *   ckpt: the buffer the forward filled (required). */
+int ss2d_selective_scan_bwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                            const void *C, const float *D, const void *z, const float *delta_bias,
+                            const void *dout, const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
+                            float *dC, float *dD, void *dz, float *ddelta_bias, int batch, int dim, int L,
+                            int dstate, int ngroups, int delta_softplus, void *stream);
+
+/* CrossScan (mamba_sys.py:403-404): x (B, D, H, W) -> xs (B, 4, D, H*W); _bwd is its adjoint
+ * (sums the four directions back into dx). */
+int ss2d_cross_scan_fwd(int dtype, const void *x, void *xs, int B, int D, int H, int W, void *stream);
+int ss2d_cross_scan_bwd(int dtype, const void *dxs, void *dx, int B, int D, int H, int W, void *stream);
+
+/* CrossMerge (mamba_sys.py:445-449): ys (B, 4, D, H*W) -> y; channel_last=1 writes (B, H, W, D)
+ * (what :449 produces), 0 writes (B, D, H*W).  _bwd scatters dy to the four directions. */
+int ss2d_cross_merge_fwd(int dtype, const void *ys, void *y, int B, int D, int H, int W, int channel_last,
+                         void *stream);
+int ss2d_cross_merge_bwd(int dtype, const void *dy, void *dys, int B, int D, int H, int W, int channel_last,
+                         void *stream);
+
+/* Depthwise 3x3 conv (pad 1, bias) + SiLU (mamba_sys.py:299-308, :558-559).
+ *   x: channel_last_in ? (B, H, W, ldx) with the D channels first (ldx >= D lets it read the x half of
+ *      the in_proj output xz directly, ldx = 2*D) : (B, D, H, W);  w (D, 3, 3); bias (D) nullable;
+ *   y (B, D, H, W).  _bwd: dy (B, D, H, W) -> dx (same layout as x, row stride lddx), dw, dbias
+ *   (accumulated into with float atomics: caller zero-fills dw/dbias). */
+int ss2d_dwconv3x3_silu_fwd(int dtype, const void *x, const float *w, const float *bias, void *y, int B, int D,
+                            int H, int W, int channel_last_in, int ldx, void *stream);
+int ss2d_dwconv3x3_silu_bwd(int dtype, const void *x, const float *w, const float *bias, const void *dy,
+                            void *dx, float *dw, float *dbias, int B, int D, int H, int W, int channel_last_in,
+                            int ldx, int lddx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

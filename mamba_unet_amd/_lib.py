@@ -1,0 +1,66 @@
+"""ctypes binding of libss2d_hip.so (C ABI declared in include/ss2d.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libss2d_hip.so")
+ABI_VERSION = 1
+
+_vp, _fp, _i, _sz = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+
+_SIGNATURES = {
+    "ss2d_abi_version": (_i, []),
+    "ss2d_last_error": (ctypes.c_char_p, []),
+    "ss2d_scan_num_chunks": (_i, [_i]),
+    "ss2d_scan_ckpt_bytes": (_sz, [_i, _i, _i, _i]),
+    "ss2d_selective_scan_fwd": (_i, [_i] + [_vp] * 11 + [_i] * 6 + [_vp]),
+    "ss2d_selective_scan_bwd": (_i, [_i] + [_vp] * 18 + [_i] * 6 + [_vp]),
+    "ss2d_cross_scan_fwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ss2d_cross_scan_bwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "ss2d_cross_merge_fwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ss2d_cross_merge_bwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ss2d_dwconv3x3_silu_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ss2d_dwconv3x3_silu_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class SS2DLibraryError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SS2DLibraryError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C mamba_unet_amd/csrc`")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        if lib.ss2d_abi_version() != ABI_VERSION:
+            raise SS2DLibraryError(f"ABI mismatch: library {lib.ss2d_abi_version()} != binding {ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().ss2d_last_error().decode(errors="replace")
+        if rc < 0:
+            raise ValueError(f"{what}: {msg} (rc={rc})")
+        raise RuntimeError(f"{what}: {msg} (hipError {rc})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())

@@ -1,0 +1,80 @@
+// Shared device helpers for the SS2D kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+#define SS2D_LOG2E 1.4426950408889634f
+#define SS2D_LN2 0.6931471805599453f
+
+__device__ __forceinline__ float hw_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+__device__ __forceinline__ float hw_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+__device__ __forceinline__ float hw_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat2(float x) { return f2{x, x}; }
+__device__ __forceinline__ f2 exp2_2(f2 x) { return f2{hw_exp2(x.x), hw_exp2(x.y)}; }
+
+// softplus(x) with torch's threshold 20; also returns sigmoid(x) (= d softplus / dx) when asked.
+// log1p(e) is evaluated as log(w) * e / (w - 1), w = 1 + e, which keeps full relative accuracy for the
+// small e (delta ~ 1e-3) this model lives on.
+template <bool WANT_SIG>
+__device__ __forceinline__ float softplus_sig(float x, float &sig) {
+    const float e = hw_exp2(x * SS2D_LOG2E);
+    const float w = 1.0f + e;
+    const float d = w - 1.0f;
+    const float lg = hw_log2(w) * SS2D_LN2;
+    float r = (d == 0.0f) ? e : lg * (e * hw_rcp(d));
+    if (WANT_SIG) sig = (x > 20.0f) ? 1.0f : e * hw_rcp(w);
+    return (x > 20.0f) ? x : r;
+}
+
+// x * sigmoid(x) and its derivative pieces
+__device__ __forceinline__ float sigmoidf_fast(float x) { return hw_rcp(1.0f + hw_exp2(-x * SS2D_LOG2E)); }
+
+template <int CTRL, int ROW_MASK, bool BOUND_ZERO>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 CTRL, ROW_MASK, 0xf, BOUND_ZERO));
+}
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_ROW_SHL(n) (0x100 + (n))
+#define DPP_ROW_ROR(n) (0x120 + (n))
+
+// XCD-aware bijective remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs,
+// so logical ids that should share an L2 (same B/C tile) are made consecutive within one XCD.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (orig >> 3);
+}
+
+// 8 consecutive floats per lane, zero-filled past `L`.  VEC4 needs (row base + p0) 16-byte aligned and L % 4 == 0.
+template <bool VEC4>
+__device__ __forceinline__ void load8(const float *__restrict__ row, int p0, int L, bool ok, float (&v)[8]) {
+    if (VEC4) {
+        f4 a = f4{0, 0, 0, 0}, b = f4{0, 0, 0, 0};
+        if (ok && p0 < L) a = *reinterpret_cast<const f4 *>(row + p0);
+        if (ok && p0 + 4 < L) b = *reinterpret_cast<const f4 *>(row + p0 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = (ok && p0 + t < L) ? row[p0 + t] : 0.0f;
+    }
+}
+template <bool VEC4>
+__device__ __forceinline__ void store8(float *__restrict__ row, int p0, int L, bool ok, const float (&v)[8]) {
+    if (VEC4) {
+        if (ok && p0 < L) *reinterpret_cast<f4 *>(row + p0) = f4{v[0], v[1], v[2], v[3]};
+        if (ok && p0 + 4 < L) *reinterpret_cast<f4 *>(row + p0 + 4) = f4{v[4], v[5], v[6], v[7]};
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (ok && p0 + t < L) row[p0 + t] = v[t];
+    }
+}
+
+// thread-local error string shared by the C-ABI entry points
+void ss2d_set_error(const char *fmt, ...);

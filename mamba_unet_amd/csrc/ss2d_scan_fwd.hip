@@ -1,0 +1,241 @@
+// Selective scan (S6 recurrence) forward for gfx950 -- the `selective_scan_fn` half of the SS2D hot path
+// (/root/reference/code/networks/mamba_sys.py:436-442; semantics :62-144).
+//
+// Decomposition ("X16"): a wavefront holds 4 rows of 16 lanes; a row is one (batch, channel) sequence,
+// each lane owns T=8 consecutive positions, so a wave advances 4 channels by 128 positions per chunk.
+//   * thread-local recurrence over the lane's 8 items, states handled two at a time as float2
+//     (v_pk_mul_f32 / v_pk_fma_f32);
+//   * 4-step Hillis-Steele scan of the (decay, state) pairs across the 16 lanes of a row with DPP
+//     row_shr modifiers folded into v_fmac/v_mul (no LDS, no cross-row traffic);
+//   * second local pass from the lane's true incoming state, fused with y += C*h;
+//   * the state leaving a chunk is rotated to lane 0 of the row (row_ror:1) for the next chunk.
+// B and C of the (batch, group) are shared by every channel of the group: the workgroup stages the
+// chunk's B/C tile once in LDS, interleaving state pairs so one ds_read_b128 feeds two packed FMAs.
+// The product of exp(delta*A) over a lane's items is exp(A * sum(delta)), so the lane aggregate costs
+// one exp instead of seven multiplies.
+#include "ss2d_common.h"
+#include "../../include/ss2d.h"
+
+namespace {
+
+constexpr int T = 8;          // items per lane
+constexpr int CHUNK = 128;    // positions per row per chunk = 16 lanes * T
+constexpr int NP = 8;         // state pairs (dstate <= 16; odd/short dstate padded with inert states)
+static_assert(CHUNK == SS2D_SCAN_CHUNK, "checkpoint spacing is part of the ABI");
+
+struct ScanFwdParams {
+    const float *u, *delta, *A, *B, *C, *D, *z, *bias;
+    float *out, *last, *ckpt;
+    int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg;
+};
+
+// Inclusive scan of (a, h) over the 16 lanes of each DPP row, two independent states interleaved so
+// that every DPP read is >= 2 instructions behind the write of its source (hardware hazard).
+__device__ __forceinline__ void row_scan_pair(float &hx, float &hy, float &ax, float &ay) {
+#define SS2D_STEP(n)                                                                   \
+    "v_fmac_f32_dpp %0, %0, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_fmac_f32_dpp %1, %1, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_mul_f32_dpp %2, %2, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_mul_f32_dpp %3, %3, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"
+    asm volatile("s_nop 1\n\t" SS2D_STEP(1) SS2D_STEP(2) SS2D_STEP(4)
+                 "v_fmac_f32_dpp %0, %0, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %1, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 : "+v"(hx), "+v"(hy), "+v"(ax), "+v"(ay));
+#undef SS2D_STEP
+}
+
+template <int NW, bool HAS_Z, bool VEC4>
+__global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdParams p) {
+    // [buffer][B|C][(pair*4 + quarter)*16 + seg] ; one f4 = (n,t),(n+1,t),(n,t+1),(n+1,t+1)
+    __shared__ f4 tile[2][2][NP * 4 * 16];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, seg = lane & 15;
+    int blk = xcd_remap(blockIdx.x, p.nwg);
+    const int cb = blk % p.wgs_per_group;
+    blk /= p.wgs_per_group;
+    const int g = blk % p.G, b = blk / p.G;
+    const int c_in_g = cb * (NW * 4) + wave * 4 + row;
+    const bool row_ok = c_in_g < p.dpg;
+    const int c = g * p.dpg + (row_ok ? c_in_g : 0);
+    const int L = p.L, N = p.N;
+
+    const size_t rowoff = ((size_t)b * p.dim + c) * (size_t)L;
+    const float *__restrict__ urow = p.u + rowoff;
+    const float *__restrict__ drow = p.delta + rowoff;
+    const float *__restrict__ zrow = HAS_Z ? p.z + rowoff : nullptr;
+    float *__restrict__ orow = p.out + rowoff;
+    const float *__restrict__ Bg = p.B + (size_t)(b * p.G + g) * N * (size_t)L;
+    const float *__restrict__ Cg = p.C + (size_t)(b * p.G + g) * N * (size_t)L;
+
+    f2 A2[NP], carry[NP];
+#pragma unroll
+    for (int np = 0; np < NP; ++np) {
+        const float a0 = (2 * np < N) ? p.A[(size_t)c * N + 2 * np] : 0.0f;
+        const float a1 = (2 * np + 1 < N) ? p.A[(size_t)c * N + 2 * np + 1] : 0.0f;
+        A2[np] = f2{a0, a1} * SS2D_LOG2E;
+        carry[np] = f2{0.0f, 0.0f};
+    }
+    const float Dc = p.D ? p.D[c] : 0.0f;
+    const float bias = p.bias ? p.bias[c] : 0.0f;
+
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int buf = chunk & 1;
+        const int base = chunk * CHUNK;
+        // ---- stage the chunk's B/C tile (shared by all waves of the workgroup)
+        for (int it = tid; it < NP * 32; it += NW * 64) {
+            const int np = it >> 5, q4 = it & 31;
+            const int pos = base + q4 * 4;
+            const int n0 = 2 * np, n1 = 2 * np + 1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float *__restrict__ M = m ? Cg : Bg;
+                f4 lo = f4{0, 0, 0, 0}, hi = f4{0, 0, 0, 0};
+                if (VEC4) {
+                    if (pos < L) {
+                        if (n0 < N) lo = *reinterpret_cast<const f4 *>(M + (size_t)n0 * L + pos);
+                        if (n1 < N) hi = *reinterpret_cast<const f4 *>(M + (size_t)n1 * L + pos);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (pos + e < L) {
+                            if (n0 < N) lo[e] = M[(size_t)n0 * L + pos + e];
+                            if (n1 < N) hi[e] = M[(size_t)n1 * L + pos + e];
+                        }
+                    }
+                }
+                const int j0 = (q4 & 1) * 2, sg = q4 >> 1;
+                tile[buf][m][(np * 4 + j0) * 16 + sg] = f4{lo.x, hi.x, lo.y, hi.y};
+                tile[buf][m][(np * 4 + j0 + 1) * 16 + sg] = f4{lo.z, hi.z, lo.w, hi.w};
+            }
+        }
+        // ---- this lane's 8 positions of u / delta
+        const int p0 = base + seg * T;
+        float uv[T], dt[T], du[T];
+        load8<VEC4>(urow, p0, L, row_ok, uv);
+        load8<VEC4>(drow, p0, L, row_ok, dt);
+        float S = 0.0f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float x = dt[t] + bias, sg_unused;
+            if (p.softplus) x = softplus_sig<false>(x, sg_unused);
+            x = (row_ok && p0 + t < L) ? x : 0.0f;  // positions past L act as the identity (a = 1, b = 0)
+            dt[t] = x;
+            du[t] = x * uv[t];
+            S += x;
+        }
+        f2 y2[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) y2[t] = f2{Dc * uv[t], 0.0f};
+
+        __syncthreads();  // tile[buf] complete; the other buffer is free for the next chunk's staging
+
+        float *ck = p.ckpt ? p.ckpt + (((size_t)b * p.dim + c) * p.nchunks + chunk) * N : nullptr;
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            if (2 * np < N) {  // wave-uniform
+                if (ck != nullptr && seg == 0 && row_ok) {
+                    ck[2 * np] = carry[np].x;
+                    if (2 * np + 1 < N) ck[2 * np + 1] = carry[np].y;
+                }
+                f2 a[T], bb[T];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f4 Bq = tile[buf][0][(np * 4 + j) * 16 + seg];
+                    bb[2 * j] = splat2(du[2 * j]) * f2{Bq.x, Bq.y};
+                    bb[2 * j + 1] = splat2(du[2 * j + 1]) * f2{Bq.z, Bq.w};
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) a[t] = exp2_2(splat2(dt[t]) * A2[np]);
+                // pass 1: lane-local recurrence (lane 0 of the row starts from the carried state)
+                f2 h = f2{seg == 0 ? carry[np].x : 0.0f, seg == 0 ? carry[np].y : 0.0f};
+#pragma unroll
+                for (int t = 0; t < T; ++t) h = fma2(a[t], h, bb[t]);
+                f2 at = exp2_2(splat2(S) * A2[np]);
+                float hx = h.x, hy = h.y, ax = at.x, ay = at.y;
+                row_scan_pair(hx, hy, ax, ay);
+                // state entering this lane = inclusive result of the lane to the left (carry for lane 0)
+                h.x = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(carry[np].x, hx);
+                h.y = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(carry[np].y, hy);
+                // pass 2: true states, fused with the C contraction
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f4 Cq = tile[buf][1][(np * 4 + j) * 16 + seg];
+                    h = fma2(a[2 * j], h, bb[2 * j]);
+                    y2[2 * j] = fma2(f2{Cq.x, Cq.y}, h, y2[2 * j]);
+                    h = fma2(a[2 * j + 1], h, bb[2 * j + 1]);
+                    y2[2 * j + 1] = fma2(f2{Cq.z, Cq.w}, h, y2[2 * j + 1]);
+                }
+                carry[np].x = dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, h.x);
+                carry[np].y = dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, h.y);
+            }
+        }
+        float yv[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) yv[t] = y2[t].x + y2[t].y;
+        if (HAS_Z) {
+            float zv[T];
+            load8<VEC4>(zrow, p0, L, row_ok, zv);
+#pragma unroll
+            for (int t = 0; t < T; ++t) yv[t] *= zv[t] * sigmoidf_fast(zv[t]);
+        }
+        store8<VEC4>(orow, p0, L, row_ok, yv);
+    }
+    if (p.last != nullptr && seg == 0 && row_ok) {
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            if (2 * np < N) p.last[((size_t)b * p.dim + c) * N + 2 * np] = carry[np].x;
+            if (2 * np + 1 < N) p.last[((size_t)b * p.dim + c) * N + 2 * np + 1] = carry[np].y;
+        }
+    }
+}
+
+template <int NW>
+int launch_fwd(const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
+    dim3 grid(p.nwg), block(NW * 64);
+    if (has_z) {
+        if (vec4) hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, true, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, true, false>), grid, block, 0, s, p);
+    } else {
+        if (vec4) hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, true>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, false>), grid, block, 0, s, p);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" int ss2d_scan_num_chunks(int L) { return (L + CHUNK - 1) / CHUNK; }
+
+extern "C" size_t ss2d_scan_ckpt_bytes(int batch, int dim, int L, int dstate) {
+    return (size_t)batch * dim * ss2d_scan_num_chunks(L) * dstate * sizeof(float);
+}
+
+extern "C" int ss2d_selective_scan_fwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                       const void *C, const float *D, const void *z, const float *delta_bias,
+                                       void *out, float *last_state, float *ckpt, int batch, int dim, int L,
+                                       int dstate, int ngroups, int delta_softplus, void *stream) {
+    if (dtype != SS2D_DTYPE_F32) { ss2d_set_error("selective_scan_fwd: dtype %d not supported (fp32 only)", dtype); return -1; }
+    if (!u || !delta || !A || !B || !C || !out) { ss2d_set_error("selective_scan_fwd: null required pointer"); return -2; }
+    if (batch <= 0 || dim <= 0 || L <= 0 || dstate <= 0 || ngroups <= 0) { ss2d_set_error("selective_scan_fwd: non-positive size"); return -3; }
+    if (dstate > SS2D_MAX_DSTATE) { ss2d_set_error("selective_scan_fwd: dstate %d > %d", dstate, SS2D_MAX_DSTATE); return -4; }
+    if (dim % ngroups) { ss2d_set_error("selective_scan_fwd: dim %d not divisible by ngroups %d", dim, ngroups); return -5; }
+    ScanFwdParams p;
+    p.u = (const float *)u; p.delta = (const float *)delta; p.A = A; p.B = (const float *)B; p.C = (const float *)C;
+    p.D = D; p.z = (const float *)z; p.bias = delta_bias; p.out = (float *)out; p.last = last_state; p.ckpt = ckpt;
+    p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
+    p.nchunks = ss2d_scan_num_chunks(L); p.softplus = delta_softplus;
+    const int nw = p.dpg >= 16 ? 4 : (p.dpg >= 8 ? 2 : 1);
+    p.wgs_per_group = (p.dpg + nw * 4 - 1) / (nw * 4);
+    const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
+    if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_fwd: grid too large"); return -6; }
+    p.nwg = (int)nwg;
+    const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)out |
+                                         (uintptr_t)z) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = nw == 4 ? launch_fwd<4>(p, z != nullptr, vec4, s) : nw == 2 ? launch_fwd<2>(p, z != nullptr, vec4, s)
+                                                                            : launch_fwd<1>(p, z != nullptr, vec4, s);
+    if (rc) ss2d_set_error("selective_scan_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}

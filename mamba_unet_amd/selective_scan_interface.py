@@ -1,0 +1,124 @@
+"""`selective_scan_fn` -- drop-in for mamba_ssm.ops.selective_scan_interface.selective_scan_fn as the
+reference imports it (code/networks/mamba_sys.py:17-20) and calls it (:436-442).
+
+Same signature, argument meaning and return convention as upstream; every FLOP runs in the HIP
+kernels of libss2d_hip.so through the C ABI of include/ss2d.h.  CPU tensors are rejected: there is
+no fallback path."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_F32 = 0
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _prep(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"selective_scan_fn: `{name}` must be a GPU tensor (no CPU path in mamba_unet_amd)")
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+class SelectiveScanFn(torch.autograd.Function):
+    """autograd wrapper; keeps upstream's class name so `prim::PythonOp.SelectiveScanFn`
+    (mamba_sys.py:864) still resolves."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                return_last_state=False):
+        if A.is_complex():
+            raise NotImplementedError("complex A is not supported (not on the Mamba-UNet path, mamba_sys.py:57)")
+        if u.dim() != 3 or delta.shape != u.shape:
+            raise ValueError(f"u/delta must be (batch, dim, L) and equal: {tuple(u.shape)} vs {tuple(delta.shape)}")
+        in_dtype = u.dtype
+        batch, dim, L = u.shape
+        dstate = A.shape[1]
+        if A.shape[0] != dim:
+            raise ValueError(f"A must be (dim, dstate) = ({dim}, n), got {tuple(A.shape)}")
+        if B.dim() not in (3, 4) or C.dim() not in (3, 4):
+            raise NotImplementedError("only input-dependent B/C of shape (b, n, l) or (b, g, n, l) are supported")
+        ctx.squeeze_B, ctx.squeeze_C = B.dim() == 3, C.dim() == 3
+        B4 = B.unsqueeze(1) if B.dim() == 3 else B
+        C4 = C.unsqueeze(1) if C.dim() == 3 else C
+        G = B4.shape[1]
+        if C4.shape != B4.shape or B4.shape != (batch, G, dstate, L):
+            raise ValueError(f"B/C must be (batch, [groups,] dstate, L): {tuple(B.shape)} / {tuple(C.shape)}")
+        if dim % G:
+            raise ValueError(f"dim {dim} not divisible by groups {G}")
+        for nm, v in (("D", D), ("delta_bias", delta_bias)):
+            if v is not None and v.shape != (dim,):
+                raise ValueError(f"{nm} must be ({dim},), got {tuple(v.shape)}")
+        if z is not None and z.shape != u.shape:
+            raise ValueError("z must have u's shape")
+
+        u_, delta_ = _prep(u, "u"), _prep(delta, "delta")
+        A_, B_, C_ = _prep(A, "A"), _prep(B4, "B"), _prep(C4, "C")
+        D_, z_, bias_ = _prep(D, "D"), _prep(z, "z"), _prep(delta_bias, "delta_bias")
+        needs_grad = any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
+        lib = _lib.load()
+        out = torch.empty_like(u_)
+        last = torch.empty((batch, dim, dstate), device=u_.device, dtype=torch.float32) if return_last_state else None
+        ckpt = None
+        if needs_grad:
+            ckpt = torch.empty((batch, dim, lib.ss2d_scan_num_chunks(L), dstate), device=u_.device, dtype=torch.float32)
+        with torch.cuda.device(u_.device):
+            rc = lib.ss2d_selective_scan_fwd(_F32, _lib.ptr(u_), _lib.ptr(delta_), _lib.ptr(A_), _lib.ptr(B_),
+                                             _lib.ptr(C_), _lib.ptr(D_), _lib.ptr(z_), _lib.ptr(bias_),
+                                             _lib.ptr(out), _lib.ptr(last), _lib.ptr(ckpt), batch, dim, L, dstate, G,
+                                             int(bool(delta_softplus)), _stream())
+        _lib.check(rc, "ss2d_selective_scan_fwd")
+        ctx.delta_softplus = bool(delta_softplus)
+        ctx.has = (D is not None, z is not None, delta_bias is not None)
+        ctx.in_dtypes = (u.dtype, delta.dtype, A.dtype, B.dtype, C.dtype,
+                         None if D is None else D.dtype, None if z is None else z.dtype,
+                         None if delta_bias is None else delta_bias.dtype)
+        ctx.save_for_backward(u_, delta_, A_, B_, C_, D_, z_, bias_, ckpt)
+        out = out.to(in_dtype)
+        if return_last_state:
+            ctx.mark_non_differentiable(last)
+            return out, last
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *unused):
+        u, delta, A, B, C, D, z, bias, ckpt = ctx.saved_tensors
+        batch, dim, L = u.shape
+        dstate, G = A.shape[1], B.shape[1]
+        dout = _prep(dout, "dout")
+        lib = _lib.load()
+        du, ddelta = torch.empty_like(u), torch.empty_like(u)
+        dA = torch.zeros_like(A)
+        dB, dC = torch.zeros_like(B), torch.zeros_like(C)
+        dD = torch.zeros_like(D) if D is not None else None
+        dz = torch.empty_like(z) if z is not None else None
+        dbias = torch.zeros_like(bias) if bias is not None else None
+        with torch.cuda.device(u.device):
+            rc = lib.ss2d_selective_scan_bwd(_F32, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B), _lib.ptr(C),
+                                             _lib.ptr(D), _lib.ptr(z), _lib.ptr(bias), _lib.ptr(dout), _lib.ptr(ckpt),
+                                             _lib.ptr(du), _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC),
+                                             _lib.ptr(dD), _lib.ptr(dz), _lib.ptr(dbias), batch, dim, L, dstate, G,
+                                             int(ctx.delta_softplus), _stream())
+        _lib.check(rc, "ss2d_selective_scan_bwd")
+        if ctx.squeeze_B:
+            dB = dB.squeeze(1)
+        if ctx.squeeze_C:
+            dC = dC.squeeze(1)
+        dt = ctx.in_dtypes
+        cast = lambda g, d: None if g is None else g.to(d)  # noqa: E731
+        return (cast(du, dt[0]), cast(ddelta, dt[1]), cast(dA, dt[2]), cast(dB, dt[3]), cast(dC, dt[4]),
+                cast(dD, dt[5]), cast(dz, dt[6]), cast(dbias, dt[7]), None, None)
+
+
+def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_softplus=False,
+                      return_last_state=False):
+    """u, delta (b, d, l); A (d, n); B, C (b, n, l) or (b, g, n, l); D, delta_bias (d); z (b, d, l).
+    Returns out (b, d, l) in u's dtype [, last_state (b, d, n) fp32]."""
+    return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
