@@ -1,0 +1,387 @@
+// Selective scan backward for gfx950 (autograd half of `selective_scan_fn`,
+// /root/reference/code/networks/mamba_sys.py:436-442; forward semantics :62-144).
+//
+// Same lane layout as the forward (ss2d_scan_fwd.hip): a wave = 4 channel rows x 16 lanes x 8 positions.
+// Chunks of 128 positions are walked from the END of the sequence to the start:
+//   * forward states of the chunk are recomputed from the checkpoint the forward kernel stored
+//     (state entering the chunk): local recurrence + DPP row scan, as in the forward;
+//   * the adjoint recurrence  r_l = a_l * (dy_l*C_l + r_{l+1})  (r_l = a_l * dL/dh_l) is scanned the other
+//     way with row_shl DPP steps; the value leaving the chunk on the left is carried to the next
+//     (earlier) chunk through LDS;
+//   * dB/dC are sums over the channels of a group: every lane adds its products into a per-row LDS tile
+//     (ds_add_f32, conflict-free layout), the workgroup then adds the 4 row tiles and issues ONE global
+//     float atomic per element and chunk;
+//   * dA/dD/ddelta_bias are reduced over lanes (DPP row sums), over chunks (LDS / registers) and
+//     over batch (global float atomics at the end).
+#include "ss2d_common.h"
+#include "../../include/ss2d.h"
+
+namespace {
+
+constexpr int T = 8;
+constexpr int CHUNK = 128;
+constexpr int NP = 8;
+constexpr int ACC_ROW_FLOATS = 2 * NP * 4 * 4 * 16;  // per row: [mat][np][quarter][e][seg]
+
+struct ScanBwdParams {
+    const float *u, *delta, *A, *B, *C, *D, *z, *bias, *dout, *ckpt;
+    float *du, *ddelta, *dA, *dB, *dC, *dD, *dz, *dbias;
+    int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg, rounds, cb;
+};
+
+#define SS2D_FSTEP(n)                                                                  \
+    "v_fmac_f32_dpp %0, %0, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_fmac_f32_dpp %1, %1, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_mul_f32_dpp %2, %2, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_mul_f32_dpp %3, %3, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"
+#define SS2D_RSTEP(n)                                                                  \
+    "v_fmac_f32_dpp %0, %0, %2 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_fmac_f32_dpp %1, %1, %3 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
+    "v_mul_f32_dpp %2, %2, %2 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"          \
+    "v_mul_f32_dpp %3, %3, %3 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"
+
+// inclusive prefix scan of (a, h) along the 16 lanes of a row: h_i <- h_i + a_i * h_{i-s}
+__device__ __forceinline__ void row_scan_fwd_pair(float &hx, float &hy, float &ax, float &ay) {
+    asm volatile("s_nop 1\n\t" SS2D_FSTEP(1) SS2D_FSTEP(2) SS2D_FSTEP(4)
+                 "v_fmac_f32_dpp %0, %0, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %1, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 : "+v"(hx), "+v"(hy), "+v"(ax), "+v"(ay));
+}
+// inclusive suffix scan: r_i <- r_i + a_i * r_{i+s}
+__device__ __forceinline__ void row_scan_rev_pair(float &rx, float &ry, float &ax, float &ay) {
+    asm volatile("s_nop 1\n\t" SS2D_RSTEP(1) SS2D_RSTEP(2) SS2D_RSTEP(4)
+                 "v_fmac_f32_dpp %0, %0, %2 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f32_dpp %1, %1, %3 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\t"
+                 : "+v"(rx), "+v"(ry), "+v"(ax), "+v"(ay));
+}
+// sum over the 16 lanes of a row; the total lands in lane 15 of the row
+__device__ __forceinline__ float row_sum_to_lane15(float v) {
+    v += dpp_mov<DPP_ROW_SHR(1), 0xf, true>(0.0f, v);
+    v += dpp_mov<DPP_ROW_SHR(2), 0xf, true>(0.0f, v);
+    v += dpp_mov<DPP_ROW_SHR(4), 0xf, true>(0.0f, v);
+    v += dpp_mov<DPP_ROW_SHR(8), 0xf, true>(0.0f, v);
+    return v;
+}
+
+template <int NW, bool HAS_Z, bool VEC4>
+__global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    f4 *tile = reinterpret_cast<f4 *>(smem);                                   // [2][NP*4*16] f4 = 16 KB
+    float *acc = reinterpret_cast<float *>(smem + 2 * NP * 4 * 16 * sizeof(f4));  // [4][ACC_ROW_FLOATS] = 64 KB
+    f2 *rc = reinterpret_cast<f2 *>(acc + 4 * ACC_ROW_FLOATS);                 // [NW*rounds][NP][4 rows]
+    float *dAs = reinterpret_cast<float *>(rc + NW * p.rounds * NP * 4);       // [NW*rounds][4 rows][16]
+    float *dXs = dAs + NW * p.rounds * 64;                                     // [NW*rounds][4 rows][2] : dD, dbias
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, seg = lane & 15;
+    int blk = xcd_remap(blockIdx.x, p.nwg);
+    const int cbi = blk % p.wgs_per_group;
+    blk /= p.wgs_per_group;
+    const int g = blk % p.G, b = blk / p.G;
+    const int L = p.L, N = p.N;
+    const float *__restrict__ Bg = p.B + (size_t)(b * p.G + g) * N * (size_t)L;
+    const float *__restrict__ Cg = p.C + (size_t)(b * p.G + g) * N * (size_t)L;
+    float *__restrict__ dBg = p.dB + (size_t)(b * p.G + g) * N * (size_t)L;
+    float *__restrict__ dCg = p.dC + (size_t)(b * p.G + g) * N * (size_t)L;
+
+    // zero the LDS accumulators / carries
+    for (int i = tid; i < 4 * ACC_ROW_FLOATS; i += NW * 64) acc[i] = 0.0f;
+    for (int i = tid; i < NW * p.rounds * NP * 4; i += NW * 64) rc[i] = f2{0.0f, 0.0f};
+    for (int i = tid; i < NW * p.rounds * (64 + 8); i += NW * 64) dAs[i] = 0.0f;  // dAs and dXs are contiguous
+
+    for (int chunk = p.nchunks - 1; chunk >= 0; --chunk) {
+        const int base = chunk * CHUNK;
+        __syncthreads();  // previous flush done, acc zeroed, tile free
+        for (int it = tid; it < NP * 32; it += NW * 64) {
+            const int np = it >> 5, q4 = it & 31;
+            const int pos = base + q4 * 4;
+            const int n0 = 2 * np, n1 = 2 * np + 1;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float *__restrict__ M = m ? Cg : Bg;
+                f4 lo = f4{0, 0, 0, 0}, hi = f4{0, 0, 0, 0};
+                if (VEC4) {
+                    if (pos < L) {
+                        if (n0 < N) lo = *reinterpret_cast<const f4 *>(M + (size_t)n0 * L + pos);
+                        if (n1 < N) hi = *reinterpret_cast<const f4 *>(M + (size_t)n1 * L + pos);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (pos + e < L) {
+                            if (n0 < N) lo[e] = M[(size_t)n0 * L + pos + e];
+                            if (n1 < N) hi[e] = M[(size_t)n1 * L + pos + e];
+                        }
+                    }
+                }
+                const int j0 = (q4 & 1) * 2, sg = q4 >> 1;
+                tile[m * (NP * 64) + (np * 4 + j0) * 16 + sg] = f4{lo.x, hi.x, lo.y, hi.y};
+                tile[m * (NP * 64) + (np * 4 + j0 + 1) * 16 + sg] = f4{lo.z, hi.z, lo.w, hi.w};
+            }
+        }
+        __syncthreads();
+
+        for (int r = 0; r < p.rounds; ++r) {
+            const int quad = r * NW + wave;
+            const int c_in_g = cbi * p.cb + quad * 4 + row;
+            const bool row_ok = (quad * 4 + row < p.cb) && (c_in_g < p.dpg);
+            const int c = g * p.dpg + (row_ok ? c_in_g : 0);
+            const size_t rowoff = ((size_t)b * p.dim + c) * (size_t)L;
+            const int p0 = base + seg * T;
+            float uv[T], dt[T], sg[T], dyv[T], du_[T];
+            load8<VEC4>(p.u + rowoff, p0, L, row_ok, uv);
+            load8<VEC4>(p.delta + rowoff, p0, L, row_ok, dt);
+            load8<VEC4>(p.dout + rowoff, p0, L, row_ok, dyv);
+            const float bias = p.bias ? p.bias[c] : 0.0f;
+            const float Dc = p.D ? p.D[c] : 0.0f;
+            float S = 0.0f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                float x = dt[t] + bias, s_ = 1.0f;
+                if (p.softplus) x = softplus_sig<true>(x, s_);
+                const bool ok = row_ok && (p0 + t < L);
+                dt[t] = ok ? x : 0.0f;
+                sg[t] = s_;
+                du_[t] = dt[t] * uv[t];
+                S += dt[t];
+            }
+            const float *ck = p.ckpt + (((size_t)b * p.dim + c) * p.nchunks + chunk) * N;
+            const float *Arow = p.A + (size_t)c * N;
+            float *accrow = acc + row * ACC_ROW_FLOATS;
+
+            float zs[T], zv[T];  // silu(z) and z when gated
+            if (HAS_Z) {
+                // gate: out = y * silu(z) with y = sum_n C h + D u, so y has to be rebuilt first
+                load8<VEC4>(p.z + rowoff, p0, L, row_ok, zv);
+                f2 y2[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) y2[t] = f2{Dc * uv[t], 0.0f};
+#pragma unroll 1
+                for (int np = 0; np < NP; ++np) {
+                    if (2 * np >= N) break;
+                    const f2 A2 = f2{Arow[2 * np], (2 * np + 1 < N) ? Arow[2 * np + 1] : 0.0f} * SS2D_LOG2E;
+                    const f2 hin = f2{ck[2 * np], (2 * np + 1 < N) ? ck[2 * np + 1] : 0.0f};
+                    f2 a[T], bb[T];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f4 Bq = tile[(np * 4 + j) * 16 + seg];
+                        bb[2 * j] = splat2(du_[2 * j]) * f2{Bq.x, Bq.y};
+                        bb[2 * j + 1] = splat2(du_[2 * j + 1]) * f2{Bq.z, Bq.w};
+                    }
+#pragma unroll
+                    for (int t = 0; t < T; ++t) a[t] = exp2_2(splat2(dt[t]) * A2);
+                    f2 h = f2{seg == 0 ? hin.x : 0.0f, seg == 0 ? hin.y : 0.0f};
+#pragma unroll
+                    for (int t = 0; t < T; ++t) h = fma2(a[t], h, bb[t]);
+                    f2 at = exp2_2(splat2(S) * A2);
+                    float hx = h.x, hy = h.y, ax = at.x, ay = at.y;
+                    row_scan_fwd_pair(hx, hy, ax, ay);
+                    h.x = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(hin.x, hx);
+                    h.y = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(hin.y, hy);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f4 Cq = tile[NP * 64 + (np * 4 + j) * 16 + seg];
+                        h = fma2(a[2 * j], h, bb[2 * j]);
+                        y2[2 * j] = fma2(f2{Cq.x, Cq.y}, h, y2[2 * j]);
+                        h = fma2(a[2 * j + 1], h, bb[2 * j + 1]);
+                        y2[2 * j + 1] = fma2(f2{Cq.z, Cq.w}, h, y2[2 * j + 1]);
+                    }
+                }
+                float dzv[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const float y = y2[t].x + y2[t].y;
+                    const float s_ = sigmoidf_fast(zv[t]);
+                    zs[t] = zv[t] * s_;
+                    dzv[t] = dyv[t] * y * (s_ * (1.0f + zv[t] * (1.0f - s_)));
+                    dyv[t] *= zs[t];
+                }
+                store8<VEC4>(p.dz + rowoff, p0, L, row_ok, dzv);
+            }
+
+            f2 ddt2[T], ddu2[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) { ddt2[t] = f2{0, 0}; ddu2[t] = f2{0, 0}; }
+
+#pragma unroll 1
+            for (int np = 0; np < NP; ++np) {
+                if (2 * np >= N) break;
+                const f2 A2 = f2{Arow[2 * np], (2 * np + 1 < N) ? Arow[2 * np + 1] : 0.0f} * SS2D_LOG2E;
+                const f2 hin = f2{ck[2 * np], (2 * np + 1 < N) ? ck[2 * np + 1] : 0.0f};
+                const f2 rcar = rc[(quad * NP + np) * 4 + row];
+                f2 a[T], h[T], Bv[T], Cv[T];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f4 Bq = tile[(np * 4 + j) * 16 + seg];
+                    const f4 Cq = tile[NP * 64 + (np * 4 + j) * 16 + seg];
+                    Bv[2 * j] = f2{Bq.x, Bq.y}; Bv[2 * j + 1] = f2{Bq.z, Bq.w};
+                    Cv[2 * j] = f2{Cq.x, Cq.y}; Cv[2 * j + 1] = f2{Cq.z, Cq.w};
+                }
+#pragma unroll
+                for (int t = 0; t < T; ++t) a[t] = exp2_2(splat2(dt[t]) * A2);
+                const f2 at = exp2_2(splat2(S) * A2);
+                // ---- forward states of the chunk
+                f2 hl = f2{seg == 0 ? hin.x : 0.0f, seg == 0 ? hin.y : 0.0f};
+#pragma unroll
+                for (int t = 0; t < T; ++t) hl = fma2(a[t], hl, splat2(du_[t]) * Bv[t]);
+                float hx = hl.x, hy = hl.y, ax = at.x, ay = at.y;
+                row_scan_fwd_pair(hx, hy, ax, ay);
+                f2 hstart;
+                hstart.x = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(hin.x, hx);
+                hstart.y = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(hin.y, hy);
+                {
+                    f2 hh = hstart;
+#pragma unroll
+                    for (int t = 0; t < T; ++t) { hh = fma2(a[t], hh, splat2(du_[t]) * Bv[t]); h[t] = hh; }
+                }
+                // ---- adjoint: lane-local suffix recurrence, row scan, then the true pass
+                f2 rl = f2{seg == 15 ? rcar.x : 0.0f, seg == 15 ? rcar.y : 0.0f};
+#pragma unroll
+                for (int t = T - 1; t >= 0; --t) rl = a[t] * fma2(splat2(dyv[t]), Cv[t], rl);
+                float rx = rl.x, ry = rl.y;
+                ax = at.x; ay = at.y;
+                row_scan_rev_pair(rx, ry, ax, ay);
+                f2 rr;
+                rr.x = dpp_mov<DPP_ROW_SHL(1), 0xf, false>(rcar.x, rx);
+                rr.y = dpp_mov<DPP_ROW_SHL(1), 0xf, false>(rcar.y, ry);
+                f2 dAp = f2{0.0f, 0.0f};
+#pragma unroll
+                for (int t = T - 1; t >= 0; --t) {
+                    const f2 dh = fma2(splat2(dyv[t]), Cv[t], rr);  // dL/dh_t
+                    rr = a[t] * dh;                                  // a_t * dL/dh_t, flows to t-1
+                    const f2 dCc = splat2(dyv[t]) * h[t];
+                    const f2 dBc = splat2(du_[t]) * dh;
+                    ddu2[t] = fma2(dh, Bv[t], ddu2[t]);
+                    const f2 hp = (t > 0) ? h[t - 1] : hstart;
+                    const f2 w = rr * hp;                            // dL/da_t * a_t
+                    ddt2[t] = fma2(w, A2, ddt2[t]);                  // in log2 units; scaled by ln2 below
+                    dAp = fma2(w, splat2(dt[t]), dAp);
+                    // LDS accumulation: [mat][np][quarter][e][seg], e = (t&1)*2 + state
+                    const int j = t >> 1, e0 = (t & 1) * 2;
+                    float *aB = accrow + (((0 * NP + np) * 4 + j) * 4 + e0) * 16 + seg;
+                    float *aC = accrow + (((1 * NP + np) * 4 + j) * 4 + e0) * 16 + seg;
+                    atomicAdd(aB, dBc.x); atomicAdd(aB + 16, dBc.y);
+                    atomicAdd(aC, dCc.x); atomicAdd(aC + 16, dCc.y);
+                }
+                // value leaving the chunk on the left: carried to the previous chunk's lane 15
+                const float cx = dpp_mov<DPP_ROW_ROR(15), 0xf, false>(0.0f, rr.x);  // lane 15 <- lane 0
+                const float cy = dpp_mov<DPP_ROW_ROR(15), 0xf, false>(0.0f, rr.y);
+                if (seg == 15) rc[(quad * NP + np) * 4 + row] = f2{cx, cy};
+                // dA (log2 units were only used for ddt): reduce over the row, accumulate over chunks in LDS
+                const float sx = row_sum_to_lane15(dAp.x), sy = row_sum_to_lane15(dAp.y);
+                if (seg == 15) {
+                    dAs[(quad * 4 + row) * 16 + 2 * np] += sx;
+                    dAs[(quad * 4 + row) * 16 + 2 * np + 1] += sy;
+                }
+            }
+            // ---- per-position gradients
+            float duo[T], ddo[T], dD_part = 0.0f, db_part = 0.0f;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const float ddu = ddu2[t].x + ddu2[t].y;
+                float ddt = (ddt2[t].x + ddt2[t].y) * SS2D_LN2 + ddu * uv[t];
+                duo[t] = ddu * dt[t] + dyv[t] * Dc;
+                if (p.softplus) ddt *= sg[t];
+                const bool ok = row_ok && (p0 + t < L);
+                ddo[t] = ok ? ddt : 0.0f;
+                dD_part += dyv[t] * uv[t];
+                db_part += ddo[t];
+            }
+            store8<VEC4>(p.du + rowoff, p0, L, row_ok, duo);
+            store8<VEC4>(p.ddelta + rowoff, p0, L, row_ok, ddo);
+            const float sD = row_sum_to_lane15(dD_part), sb = row_sum_to_lane15(db_part);
+            if (seg == 15) {
+                dXs[(quad * 4 + row) * 2] += sD;
+                dXs[(quad * 4 + row) * 2 + 1] += sb;
+            }
+        }
+        __syncthreads();
+        // ---- flush dB/dC of this chunk: add the 4 row tiles, one global atomic per element
+        for (int idx = tid; idx < 2 * 16 * CHUNK; idx += NW * 64) {
+            const int mat = idx >> 11, n = (idx >> 7) & 15, pos = idx & 127;
+            const int np = n >> 1, s = n & 1, sgm = pos >> 3, t = pos & 7, j = t >> 1, e = (t & 1) * 2 + s;
+            const int off = (((mat * NP + np) * 4 + j) * 4 + e) * 16 + sgm;
+            const float v = acc[off] + acc[ACC_ROW_FLOATS + off] + acc[2 * ACC_ROW_FLOATS + off] + acc[3 * ACC_ROW_FLOATS + off];
+            acc[off] = 0.0f; acc[ACC_ROW_FLOATS + off] = 0.0f; acc[2 * ACC_ROW_FLOATS + off] = 0.0f; acc[3 * ACC_ROW_FLOATS + off] = 0.0f;
+            if (n < N && base + pos < L) atomicAdd((mat ? dCg : dBg) + (size_t)n * L + base + pos, v);
+        }
+    }
+    __syncthreads();
+    // ---- dA / dD / ddelta_bias: sums over batch -> global atomics
+    for (int i = tid; i < NW * p.rounds * 64; i += NW * 64) {
+        const int n = i & 15, rw = (i >> 4) & 3, quad = i >> 6;
+        const int c_in_g = cbi * p.cb + quad * 4 + rw;
+        if (quad * 4 + rw < p.cb && c_in_g < p.dpg && n < N) atomicAdd(p.dA + (size_t)(g * p.dpg + c_in_g) * N + n, dAs[i]);
+    }
+    for (int i = tid; i < NW * p.rounds * 4; i += NW * 64) {
+        const int c_in_g = cbi * p.cb + i;  // i = quad*4 + row
+        if (i < p.cb && c_in_g < p.dpg) {
+            if (p.dD) atomicAdd(p.dD + g * p.dpg + c_in_g, dXs[i * 2]);
+            if (p.dbias) atomicAdd(p.dbias + g * p.dpg + c_in_g, dXs[i * 2 + 1]);
+        }
+    }
+}
+
+template <int NW, bool HAS_Z, bool VEC4>
+int launch_one(const ScanBwdParams &p, size_t lds, hipStream_t s) {
+    auto kern = scan_bwd_f32_kernel<NW, HAS_Z, VEC4>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(NW * 64), lds, s, p);
+    return (int)hipGetLastError();
+}
+template <int NW>
+int launch_bwd(const ScanBwdParams &p, bool has_z, bool vec4, size_t lds, hipStream_t s) {
+    if (has_z) return vec4 ? launch_one<NW, true, true>(p, lds, s) : launch_one<NW, true, false>(p, lds, s);
+    return vec4 ? launch_one<NW, false, true>(p, lds, s) : launch_one<NW, false, false>(p, lds, s);
+}
+
+}  // namespace
+
+extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                       const void *C, const float *D, const void *z, const float *delta_bias,
+                                       const void *dout, const float *ckpt, void *du, void *ddelta, float *dA,
+                                       float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
+                                       int dim, int L, int dstate, int ngroups, int delta_softplus, void *stream) {
+    if (dtype != SS2D_DTYPE_F32) { ss2d_set_error("selective_scan_bwd: dtype %d not supported (fp32 only)", dtype); return -1; }
+    if (!u || !delta || !A || !B || !C || !dout || !ckpt || !du || !ddelta || !dA || !dB || !dC) {
+        ss2d_set_error("selective_scan_bwd: null required pointer"); return -2; }
+    if ((z != nullptr) != (dz != nullptr)) { ss2d_set_error("selective_scan_bwd: z and dz must be given together"); return -2; }
+    if (batch <= 0 || dim <= 0 || L <= 0 || dstate <= 0 || ngroups <= 0) { ss2d_set_error("selective_scan_bwd: non-positive size"); return -3; }
+    if (dstate > SS2D_MAX_DSTATE) { ss2d_set_error("selective_scan_bwd: dstate %d > %d", dstate, SS2D_MAX_DSTATE); return -4; }
+    if (dim % ngroups) { ss2d_set_error("selective_scan_bwd: dim %d not divisible by ngroups %d", dim, ngroups); return -5; }
+    ScanBwdParams p;
+    p.u = (const float *)u; p.delta = (const float *)delta; p.A = A; p.B = (const float *)B; p.C = (const float *)C;
+    p.D = D; p.z = (const float *)z; p.bias = delta_bias; p.dout = (const float *)dout; p.ckpt = ckpt;
+    p.du = (float *)du; p.ddelta = (float *)ddelta; p.dA = dA; p.dB = dB; p.dC = dC; p.dD = D ? dD : nullptr;
+    p.dz = (float *)dz; p.dbias = delta_bias ? ddelta_bias : nullptr;
+    p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
+    p.nchunks = ss2d_scan_num_chunks(L); p.softplus = delta_softplus;
+    // channels per workgroup: NW waves x 4 rows x `rounds`
+    const int nw = p.dpg >= 32 ? 8 : (p.dpg >= 16 ? 4 : (p.dpg >= 8 ? 2 : 1));
+    const int per_round = nw * 4;
+    int rounds = 1;
+    if (p.dpg > per_round) {
+        // fewer, fatter workgroups cut the dB/dC atomic traffic; keep >= ~1 workgroup per CU when possible
+        const long long units = (long long)batch * ngroups;
+        rounds = 3;
+        while (rounds > 1 && units * ((p.dpg + per_round * rounds - 1) / (per_round * rounds)) < 192) --rounds;
+    }
+    p.rounds = rounds; p.cb = per_round * rounds;
+    p.wgs_per_group = (p.dpg + p.cb - 1) / p.cb;
+    const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
+    if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_bwd: grid too large"); return -6; }
+    p.nwg = (int)nwg;
+    const size_t lds = 2 * NP * 4 * 16 * sizeof(f4) + 4 * ACC_ROW_FLOATS * sizeof(float) +
+                       (size_t)nw * rounds * NP * 4 * sizeof(f2) + (size_t)nw * rounds * (64 + 8) * sizeof(float);
+    const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dout |
+                                         (uintptr_t)du | (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & 15) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    int rc = nw == 8 ? launch_bwd<8>(p, z != nullptr, vec4, lds, s)
+           : nw == 4 ? launch_bwd<4>(p, z != nullptr, vec4, lds, s)
+           : nw == 2 ? launch_bwd<2>(p, z != nullptr, vec4, lds, s)
+                     : launch_bwd<1>(p, z != nullptr, vec4, lds, s);
+    if (rc) ss2d_set_error("selective_scan_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}

@@ -2,7 +2,6 @@
 #include "ss2d_common.h"
 #include "../../include/ss2d.h"
 #define NOTIMPL(name) { ss2d_set_error(name ": not implemented yet"); return -100; }
-extern "C" int ss2d_selective_scan_bwd(int, const void *, const void *, const float *, const void *, const void *, const float *, const void *, const float *, const void *, const float *, void *, void *, float *, float *, float *, float *, void *, float *, int, int, int, int, int, int, void *) NOTIMPL("ss2d_selective_scan_bwd")
 extern "C" int ss2d_cross_scan_fwd(int, const void *, void *, int, int, int, int, void *) NOTIMPL("ss2d_cross_scan_fwd")
 extern "C" int ss2d_cross_scan_bwd(int, const void *, void *, int, int, int, int, void *) NOTIMPL("ss2d_cross_scan_bwd")
 extern "C" int ss2d_cross_merge_fwd(int, const void *, void *, int, int, int, int, int, void *) NOTIMPL("ss2d_cross_merge_fwd")
