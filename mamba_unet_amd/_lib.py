@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libss2d_hip.so")
+LIB_PATH = os.environ.get("SS2D_HIP_LIB", os.path.join(_HERE, "libss2d_hip.so"))  # env override: A/B builds
 ABI_VERSION = 1
 
 _vp, _fp, _i, _sz = ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t

@@ -21,7 +21,7 @@ namespace {
 constexpr int T = 8;
 constexpr int CHUNK = 128;
 constexpr int NP = 8;
-constexpr int ACC_ROW_FLOATS = 2 * NP * 4 * 4 * 16;  // per row: [mat][np][quarter][e][seg]
+constexpr int ACC_WAVE_FLOATS = NP * 2 * 4 * 64;  // per wave: [np][mat][item pair][lane], rows already summed
 
 struct ScanBwdParams {
     const float *u, *delta, *A, *B, *C, *D, *z, *bias, *dout, *ckpt;
@@ -65,12 +65,25 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
     return v;
 }
 
+// Sum four per-lane values over the 4 DPP rows of the wave: on return row r of the result holds the
+// total (over rows) of x_r.  v_permlane16_swap exchanges the odd rows of its first operand with the
+// even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the
+// second; each swap is followed by one add (1.5 VALU ops per value instead of an LDS float atomic,
+// which runs ~3 cycles PER LANE on gfx950).
+__device__ __forceinline__ float rows_reduce4(float x0, float x1, float x2, float x3) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
+    float s01 = x0 + x1, s23 = x2 + x3;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s01), "+v"(s23));
+    return s01 + s23;
+}
+
 template <int NW, bool HAS_Z, bool VEC4>
 __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     f4 *tile = reinterpret_cast<f4 *>(smem);                                   // [2][NP*4*16] f4 = 16 KB
-    float *acc = reinterpret_cast<float *>(smem + 2 * NP * 4 * 16 * sizeof(f4));  // [4][ACC_ROW_FLOATS] = 64 KB
-    f2 *rc = reinterpret_cast<f2 *>(acc + 4 * ACC_ROW_FLOATS);                 // [NW*rounds][NP][4 rows]
+    float *acc = reinterpret_cast<float *>(smem + 2 * NP * 4 * 16 * sizeof(f4));  // [NW][ACC_WAVE_FLOATS], 16 KB per wave
+    f2 *rc = reinterpret_cast<f2 *>(acc + NW * ACC_WAVE_FLOATS);                 // [NW*rounds][NP][4 rows]
     float *dAs = reinterpret_cast<float *>(rc + NW * p.rounds * NP * 4);       // [NW*rounds][4 rows][16]
     float *dXs = dAs + NW * p.rounds * 64;                                     // [NW*rounds][4 rows][2] : dD, dbias
 
@@ -86,7 +99,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
     float *__restrict__ dCg = p.dC + (size_t)(b * p.G + g) * N * (size_t)L;
 
     // zero the LDS accumulators / carries
-    for (int i = tid; i < 4 * ACC_ROW_FLOATS; i += NW * 64) acc[i] = 0.0f;
+    for (int i = tid; i < NW * ACC_WAVE_FLOATS; i += NW * 64) acc[i] = 0.0f;
     for (int i = tid; i < NW * p.rounds * NP * 4; i += NW * 64) rc[i] = f2{0.0f, 0.0f};
     for (int i = tid; i < NW * p.rounds * (64 + 8); i += NW * 64) dAs[i] = 0.0f;  // dAs and dXs are contiguous
 
@@ -148,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
             }
             const float *ck = p.ckpt + (((size_t)b * p.dim + c) * p.nchunks + chunk) * N;
             const float *Arow = p.A + (size_t)c * N;
-            float *accrow = acc + row * ACC_ROW_FLOATS;
+            float *accw = acc + wave * ACC_WAVE_FLOATS + lane;  // private to this wave: plain read-modify-write
 
             float zs[T], zv[T];  // silu(z) and z when gated
             if (HAS_Z) {
@@ -246,6 +259,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
                 rr.x = dpp_mov<DPP_ROW_SHL(1), 0xf, false>(rcar.x, rx);
                 rr.y = dpp_mov<DPP_ROW_SHL(1), 0xf, false>(rcar.y, ry);
                 f2 dAp = f2{0.0f, 0.0f};
+                f2 dBprev = f2{0.0f, 0.0f}, dCprev = f2{0.0f, 0.0f};
 #pragma unroll
                 for (int t = T - 1; t >= 0; --t) {
                     const f2 dh = fma2(splat2(dyv[t]), Cv[t], rr);  // dL/dh_t
@@ -257,12 +271,21 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
                     const f2 w = rr * hp;                            // dL/da_t * a_t
                     ddt2[t] = fma2(w, A2, ddt2[t]);                  // in log2 units; scaled by ln2 below
                     dAp = fma2(w, splat2(dt[t]), dAp);
-                    // LDS accumulation: [mat][np][quarter][e][seg], e = (t&1)*2 + state
-                    const int j = t >> 1, e0 = (t & 1) * 2;
-                    float *aB = accrow + (((0 * NP + np) * 4 + j) * 4 + e0) * 16 + seg;
-                    float *aC = accrow + (((1 * NP + np) * 4 + j) * 4 + e0) * 16 + seg;
-                    atomicAdd(aB, dBc.x); atomicAdd(aB + 16, dBc.y);
-                    atomicAdd(aC, dCc.x); atomicAdd(aC + 16, dCc.y);
+                    if (t & 1) {
+                        dBprev = dBc; dCprev = dCc;
+                    } else {
+                        // channel sum over the 4 rows for items (t+1, t) x 2 states; row r = (item t+1-(r>>1), state r&1)
+#if !defined(SS2D_ABLATE_LDSADD)
+                        const float sB = rows_reduce4(dBprev.x, dBprev.y, dBc.x, dBc.y);
+                        const float sC = rows_reduce4(dCprev.x, dCprev.y, dCc.x, dCc.y);
+                        float *aB = accw + ((np * 2 + 0) * 4 + (t >> 1)) * 64;
+                        float *aC = accw + ((np * 2 + 1) * 4 + (t >> 1)) * 64;
+                        *aB += sB;
+                        *aC += sC;
+#else
+                        asm volatile("" ::"v"(dBc.x), "v"(dBc.y), "v"(dCc.x), "v"(dCc.y), "v"(dBprev.x), "v"(dCprev.x));
+#endif
+                    }
                 }
                 // value leaving the chunk on the left: carried to the previous chunk's lane 15
                 const float cx = dpp_mov<DPP_ROW_ROR(15), 0xf, false>(0.0f, rr.x);  // lane 15 <- lane 0
@@ -300,11 +323,17 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
         // ---- flush dB/dC of this chunk: add the 4 row tiles, one global atomic per element
         for (int idx = tid; idx < 2 * 16 * CHUNK; idx += NW * 64) {
             const int mat = idx >> 11, n = (idx >> 7) & 15, pos = idx & 127;
-            const int np = n >> 1, s = n & 1, sgm = pos >> 3, t = pos & 7, j = t >> 1, e = (t & 1) * 2 + s;
-            const int off = (((mat * NP + np) * 4 + j) * 4 + e) * 16 + sgm;
-            const float v = acc[off] + acc[ACC_ROW_FLOATS + off] + acc[2 * ACC_ROW_FLOATS + off] + acc[3 * ACC_ROW_FLOATS + off];
-            acc[off] = 0.0f; acc[ACC_ROW_FLOATS + off] = 0.0f; acc[2 * ACC_ROW_FLOATS + off] = 0.0f; acc[3 * ACC_ROW_FLOATS + off] = 0.0f;
+            const int np = n >> 1, s = n & 1, sgm = pos >> 3, t = pos & 7;
+            const int rw = ((t & 1) ? 0 : 2) + s;
+            const int off = ((np * 2 + mat) * 4 + (t >> 1)) * 64 + rw * 16 + sgm;
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { v += acc[w * ACC_WAVE_FLOATS + off]; acc[w * ACC_WAVE_FLOATS + off] = 0.0f; }
+#if !defined(SS2D_ABLATE_FLUSH)
             if (n < N && base + pos < L) atomicAdd((mat ? dCg : dBg) + (size_t)n * L + base + pos, v);
+#else
+            asm volatile("" ::"v"(v));
+#endif
         }
     }
     __syncthreads();
@@ -373,7 +402,7 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
     const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
     if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_bwd: grid too large"); return -6; }
     p.nwg = (int)nwg;
-    const size_t lds = 2 * NP * 4 * 16 * sizeof(f4) + 4 * ACC_ROW_FLOATS * sizeof(float) +
+    const size_t lds = 2 * NP * 4 * 16 * sizeof(f4) + (size_t)nw * ACC_WAVE_FLOATS * sizeof(float) +
                        (size_t)nw * rounds * NP * 4 * sizeof(f2) + (size_t)nw * rounds * (64 + 8) * sizeof(float);
     const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dout |
                                          (uintptr_t)du | (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & 15) == 0);
