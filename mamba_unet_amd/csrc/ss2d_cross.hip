@@ -1,0 +1,163 @@
+// CrossScan / CrossMerge for gfx950 (/root/reference/code/networks/mamba_sys.py:403-404 and :445-449).
+//
+// With p = h*W + w (row-major) and q = w*H + h (column-major):
+//   scan : xs[b,0,d,p] = xs[b,1,d,q] = xs[b,2,d,L-1-p] = xs[b,3,d,L-1-q] = x[b,d,h,w]
+//   merge: y[b,d,h,w] = ys[b,0,d,p] + ys[b,1,d,q] + ys[b,2,d,L-1-p] + ys[b,3,d,L-1-q]
+// The two are adjoint, so cross_scan_bwd = merge and cross_merge_bwd = scan.
+// A workgroup owns a 3-D tile (32 channels x 16 rows x 16 cols) held in LDS: row-major directions are
+// touched with w on the fast lanes, column-major ones with h on the fast lanes (64-byte runs either way),
+// and a channel-last side (B,H,W,D) with d on the fast lanes (128-byte runs).
+#include "ss2d_common.h"
+#include "../../include/ss2d.h"
+
+namespace {
+
+constexpr int TD = 32, TH = 16, TW = 16;
+constexpr int SW = TW + 1;              // padded w stride
+constexpr int SD = TH * SW + 1;         // padded channel stride (odd -> conflict-free channel-fast access)
+
+struct CrossParams {
+    const float *in;   // scan: x ; merge: ys
+    float *out;        // scan: xs; merge: y
+    int B, D, H, W, tiles_h, tiles_w, tiles_d;
+};
+
+__device__ __forceinline__ void tile_coords(const CrossParams &p, int &b, int &d0, int &h0, int &w0) {
+    int blk = blockIdx.x;
+    const int tw = blk % p.tiles_w; blk /= p.tiles_w;
+    const int th = blk % p.tiles_h; blk /= p.tiles_h;
+    const int td = blk % p.tiles_d; b = blk / p.tiles_d;
+    d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+}
+
+// x side is channel-last (B,H,W,D) when CL, else (B,D,H,W)
+template <bool CL>
+__global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
+    __shared__ float s[TD * SD];
+    int b, d0, h0, w0;
+    tile_coords(p, b, d0, h0, w0);
+    const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
+    const size_t L = (size_t)H * W;
+    if (CL) {
+        for (int i = tid; i < TD * TH * TW; i += 256) {
+            const int d = i & (TD - 1), pos = i >> 5, w = pos & (TW - 1), h = pos >> 4;
+            float v = 0.0f;
+            if (d0 + d < D && h0 + h < H && w0 + w < W) v = p.in[(((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d];
+            s[d * SD + h * SW + w] = v;
+        }
+    } else {
+        for (int i = tid; i < TD * TH * TW; i += 256) {
+            const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
+            float v = 0.0f;
+            if (d0 + d < D && h0 + h < H && w0 + w < W) v = p.in[(((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w];
+            s[d * SD + h * SW + w] = v;
+        }
+    }
+    __syncthreads();
+    // row-major directions 0 and 2: w on the fast lanes
+    for (int i = tid; i < TD * TH * TW; i += 256) {
+        const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            const float v = s[d * SD + h * SW + w];
+            const size_t pp = (size_t)(h0 + h) * W + w0 + w;
+            float *o0 = p.out + (((size_t)b * 4 + 0) * D + d0 + d) * L;
+            float *o2 = p.out + (((size_t)b * 4 + 2) * D + d0 + d) * L;
+            o0[pp] = v;
+            o2[L - 1 - pp] = v;
+        }
+    }
+    // column-major directions 1 and 3: h on the fast lanes
+    for (int i = tid; i < TD * TH * TW; i += 256) {
+        const int h = i & (TH - 1), w = (i >> 4) & (TW - 1), d = i >> 8;
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            const float v = s[d * SD + h * SW + w];
+            const size_t q = (size_t)(w0 + w) * H + h0 + h;
+            float *o1 = p.out + (((size_t)b * 4 + 1) * D + d0 + d) * L;
+            float *o3 = p.out + (((size_t)b * 4 + 3) * D + d0 + d) * L;
+            o1[q] = v;
+            o3[L - 1 - q] = v;
+        }
+    }
+}
+
+template <bool CL>
+__global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
+    __shared__ float s[TD * SD];
+    int b, d0, h0, w0;
+    tile_coords(p, b, d0, h0, w0);
+    const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
+    const size_t L = (size_t)H * W;
+    for (int i = tid; i < TD * TH * TW; i += 256) {
+        const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
+        float v = 0.0f;
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            const size_t pp = (size_t)(h0 + h) * W + w0 + w;
+            const float *i0 = p.in + (((size_t)b * 4 + 0) * D + d0 + d) * L;
+            const float *i2 = p.in + (((size_t)b * 4 + 2) * D + d0 + d) * L;
+            v = i0[pp] + i2[L - 1 - pp];
+        }
+        s[d * SD + h * SW + w] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < TD * TH * TW; i += 256) {
+        const int h = i & (TH - 1), w = (i >> 4) & (TW - 1), d = i >> 8;
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            const size_t q = (size_t)(w0 + w) * H + h0 + h;
+            const float *i1 = p.in + (((size_t)b * 4 + 1) * D + d0 + d) * L;
+            const float *i3 = p.in + (((size_t)b * 4 + 3) * D + d0 + d) * L;
+            // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
+            s[d * SD + h * SW + w] = (s[d * SD + h * SW + w] + i1[q]) + i3[L - 1 - q];
+        }
+    }
+    __syncthreads();
+    if (CL) {
+        for (int i = tid; i < TD * TH * TW; i += 256) {
+            const int d = i & (TD - 1), pos = i >> 5, w = pos & (TW - 1), h = pos >> 4;
+            if (d0 + d < D && h0 + h < H && w0 + w < W)
+                p.out[(((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d] = s[d * SD + h * SW + w];
+        }
+    } else {
+        for (int i = tid; i < TD * TH * TW; i += 256) {
+            const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
+            if (d0 + d < D && h0 + h < H && w0 + w < W)
+                p.out[(((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w] = s[d * SD + h * SW + w];
+        }
+    }
+}
+
+int run(bool merge, bool cl, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name) {
+    if (dtype != SS2D_DTYPE_F32) { ss2d_set_error("%s: dtype %d not supported (fp32 only)", name, dtype); return -1; }
+    if (!in || !out) { ss2d_set_error("%s: null pointer", name); return -2; }
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
+    CrossParams p;
+    p.in = (const float *)in; p.out = (float *)out; p.B = B; p.D = D; p.H = H; p.W = W;
+    p.tiles_h = (H + TH - 1) / TH; p.tiles_w = (W + TW - 1) / TW; p.tiles_d = (D + TD - 1) / TD;
+    const long long n = (long long)B * p.tiles_d * p.tiles_h * p.tiles_w;
+    if (n > 0x7fffffffLL) { ss2d_set_error("%s: grid too large", name); return -6; }
+    hipStream_t s = (hipStream_t)stream;
+    if (merge) {
+        if (cl) hipLaunchKernelGGL(cross_merge_kernel<true>, dim3((unsigned)n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(cross_merge_kernel<false>, dim3((unsigned)n), dim3(256), 0, s, p);
+    } else {
+        if (cl) hipLaunchKernelGGL(cross_scan_kernel<true>, dim3((unsigned)n), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(cross_scan_kernel<false>, dim3((unsigned)n), dim3(256), 0, s, p);
+    }
+    const int rc = (int)hipGetLastError();
+    if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int ss2d_cross_scan_fwd(int dtype, const void *x, void *xs, int B, int D, int H, int W, void *stream) {
+    return run(false, false, dtype, x, xs, B, D, H, W, stream, "cross_scan_fwd");
+}
+extern "C" int ss2d_cross_scan_bwd(int dtype, const void *dxs, void *dx, int B, int D, int H, int W, void *stream) {
+    return run(true, false, dtype, dxs, dx, B, D, H, W, stream, "cross_scan_bwd");
+}
+extern "C" int ss2d_cross_merge_fwd(int dtype, const void *ys, void *y, int B, int D, int H, int W, int channel_last, void *stream) {
+    return run(true, channel_last != 0, dtype, ys, y, B, D, H, W, stream, "cross_merge_fwd");
+}
+extern "C" int ss2d_cross_merge_bwd(int dtype, const void *dy, void *dys, int B, int D, int H, int W, int channel_last, void *stream) {
+    return run(false, channel_last != 0, dtype, dy, dys, B, D, H, W, stream, "cross_merge_bwd");
+}

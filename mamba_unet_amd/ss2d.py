@@ -1,0 +1,216 @@
+"""SS2D / VSSBlock / VSSLayer / VSSLayer_up on the MI355X kernels.
+
+Host-side mirror of the reference's operator interface (code/networks/mamba_sys.py:267-716): same
+constructor arguments, same parameter names and shapes (checkpoint contract), same
+random-number consumption order at construction (so a given seed yields the reference's init), but
+`forward` runs:  in_proj (hipBLASLt) -> ss2d_dwconv3x3_silu (reads the channel-last x half of xz in
+place) -> ss2d_cross_scan -> x_proj / dt_proj contractions (rocBLAS batched GEMM) ->
+ss2d_selective_scan fwd/bwd -> ss2d_cross_merge (writes channel-last) -> LayerNorm, SiLU(z) gate,
+out_proj.
+"""
+from __future__ import annotations
+
+import math
+from functools import partial
+from typing import Callable
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from .selective_scan_interface import selective_scan_fn
+from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu
+
+
+class DropPath(nn.Module):
+    """Stochastic depth per sample (the reference takes it from timm, mamba_sys.py:12, :581)."""
+
+    def __init__(self, drop_prob: float = 0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        return x * mask / keep
+
+    def extra_repr(self):
+        return f"drop_prob={self.drop_prob}"
+
+
+class SS2D(nn.Module):
+    """mamba_sys.py:267-565.  Parameters: in_proj.weight (2D,C), conv2d.{weight (D,1,3,3), bias (D)},
+    x_proj_weight (4,R+2N,D), dt_projs_weight (4,D,R), dt_projs_bias (4,D), A_logs (4D,N), Ds (4D),
+    out_norm.{weight,bias} (D), out_proj.weight (C,D)."""
+
+    def __init__(self, d_model, d_state=16, d_conv=3, expand=2, dt_rank="auto", dt_min=0.001, dt_max=0.1,
+                 dt_init="random", dt_scale=1.0, dt_init_floor=1e-4, dropout=0.0, conv_bias=True, bias=False,
+                 device=None, dtype=None, **kwargs):
+        super().__init__()
+        fk = {"device": device, "dtype": dtype}
+        self.d_model, self.d_state, self.d_conv, self.expand = d_model, d_state, d_conv, expand
+        self.d_inner = int(expand * d_model)
+        self.dt_rank = math.ceil(d_model / 16) if dt_rank == "auto" else dt_rank
+        if d_conv != 3:
+            raise NotImplementedError("the HIP depthwise-conv kernel is 3x3 (the only size the reference uses)")
+        K, D, R, N = 4, self.d_inner, self.dt_rank, d_state
+
+        # creation order == random-number order of the reference (mamba_sys.py:298-337)
+        self.in_proj = nn.Linear(d_model, 2 * D, bias=bias, **fk)
+        self.conv2d = nn.Conv2d(D, D, kernel_size=d_conv, padding=(d_conv - 1) // 2, groups=D, bias=conv_bias, **fk)
+        self.act = nn.SiLU()
+        xw = [nn.Linear(D, R + 2 * N, bias=False, **fk).weight for _ in range(K)]
+        self.x_proj_weight = nn.Parameter(torch.stack(list(xw), dim=0))
+        dts = [self.dt_init(R, D, dt_scale, dt_init, dt_min, dt_max, dt_init_floor, **fk) for _ in range(K)]
+        self.dt_projs_weight = nn.Parameter(torch.stack([t.weight for t in dts], dim=0))
+        self.dt_projs_bias = nn.Parameter(torch.stack([t.bias for t in dts], dim=0))
+        self.A_logs = self.A_log_init(N, D, copies=K, merge=True)
+        self.Ds = self.D_init(D, copies=K, merge=True)
+        self.forward_core = self.forward_corev0
+        self.out_norm = nn.LayerNorm(D)
+        self.out_proj = nn.Linear(D, d_model, bias=bias, **fk)
+        self.dropout = nn.Dropout(dropout) if dropout > 0.0 else None
+
+    # ---- init statics, mamba_sys.py:340-394
+    @staticmethod
+    def dt_init(dt_rank, d_inner, dt_scale=1.0, dt_init="random", dt_min=0.001, dt_max=0.1, dt_init_floor=1e-4,
+                **factory_kwargs):
+        proj = nn.Linear(dt_rank, d_inner, bias=True, **factory_kwargs)
+        std = dt_rank ** -0.5 * dt_scale
+        if dt_init == "constant":
+            nn.init.constant_(proj.weight, std)
+        elif dt_init == "random":
+            nn.init.uniform_(proj.weight, -std, std)
+        else:
+            raise NotImplementedError(dt_init)
+        # bias = softplus^-1(dt), dt log-uniform in [dt_min, dt_max]
+        dt = torch.exp(torch.rand(d_inner, **factory_kwargs) * (math.log(dt_max) - math.log(dt_min))
+                       + math.log(dt_min)).clamp(min=dt_init_floor)
+        with torch.no_grad():
+            proj.bias.copy_(dt + torch.log(-torch.expm1(-dt)))
+        proj.bias._no_reinit = True
+        return proj
+
+    @staticmethod
+    def A_log_init(d_state, d_inner, copies=1, device=None, merge=True):
+        A_log = torch.log(torch.arange(1, d_state + 1, dtype=torch.float32, device=device)).repeat(d_inner, 1)
+        if copies > 1:
+            A_log = A_log.unsqueeze(0).repeat(copies, 1, 1)
+            if merge:
+                A_log = A_log.flatten(0, 1)
+        A_log = nn.Parameter(A_log.contiguous())
+        A_log._no_weight_decay = True
+        return A_log
+
+    @staticmethod
+    def D_init(d_inner, copies=1, device=None, merge=True):
+        Dv = torch.ones(d_inner, device=device)
+        if copies > 1:
+            Dv = Dv.unsqueeze(0).repeat(copies, 1)
+            if merge:
+                Dv = Dv.flatten(0, 1)
+        Dv = nn.Parameter(Dv.contiguous())
+        Dv._no_weight_decay = True
+        return Dv
+
+    # ---- mamba_sys.py:396-461
+    def forward_corev0(self, x: torch.Tensor):
+        """x (B, D, H, W) -> (B, H, W, D), normalised."""
+        B, D, H, W = x.shape
+        L, K, N, R = H * W, 4, self.d_state, self.dt_rank
+        xs = cross_scan(x)                                                        # (B, 4, D, L)
+        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight)
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
+        out_y = selective_scan_fn(
+            xs.float().reshape(B, K * D, L), dts.float().reshape(B, K * D, L),
+            -torch.exp(self.A_logs.float()).view(K * D, N),
+            Bs.float().reshape(B, K, N, L), Cs.float().reshape(B, K, N, L),
+            self.Ds.float().view(-1), z=None, delta_bias=self.dt_projs_bias.float().view(-1),
+            delta_softplus=True, return_last_state=False)
+        assert out_y.dtype == torch.float32
+        y = cross_merge(out_y.view(B, K, D, L), H, W, channel_last=True)         # (B, H, W, D)
+        return self.out_norm(y).to(x.dtype)
+
+    # ---- mamba_sys.py:552-565
+    def forward(self, x: torch.Tensor, **kwargs):
+        D = self.d_inner
+        xz = self.in_proj(x)                                                      # (B, H, W, 2D)
+        z = xz[..., D:]
+        xc = dwconv3x3_silu(xz[..., :D], self.conv2d.weight, self.conv2d.bias, channel_last_in=True)
+        y = self.forward_core(xc)
+        y = y * F.silu(z)
+        out = self.out_proj(y)
+        if self.dropout is not None:
+            out = self.dropout(out)
+        return out
+
+
+class VSSBlock(nn.Module):
+    """x + DropPath(SS2D(LayerNorm(x)))  (mamba_sys.py:568-585)."""
+
+    def __init__(self, hidden_dim: int = 0, drop_path: float = 0,
+                 norm_layer: Callable[..., nn.Module] = partial(nn.LayerNorm, eps=1e-6),
+                 attn_drop_rate: float = 0, d_state: int = 16, **kwargs):
+        super().__init__()
+        self.ln_1 = norm_layer(hidden_dim)
+        self.self_attention = SS2D(d_model=hidden_dim, dropout=attn_drop_rate, d_state=d_state, **kwargs)
+        self.drop_path = DropPath(drop_path)
+
+    def forward(self, input: torch.Tensor):
+        return input + self.drop_path(self.self_attention(self.ln_1(input)))
+
+
+def _burn_out_proj_rng(module: nn.Module):
+    """The reference re-initialises a detached CLONE of every SS2D.out_proj.weight right after building a
+    stage ("fake init, just to keep the seed", mamba_sys.py:627-633): no parameter changes, but the
+    generator advances.  Reproduced so that equal seeds give equal models."""
+    for m in module.modules():
+        if isinstance(m, SS2D):
+            nn.init.kaiming_uniform_(m.out_proj.weight.detach().clone(), a=math.sqrt(5))
+
+
+class _Stage(nn.Module):
+    def __init__(self, dim, depth, attn_drop, drop_path, norm_layer, use_checkpoint, d_state):
+        super().__init__()
+        self.dim, self.use_checkpoint = dim, use_checkpoint
+        self.blocks = nn.ModuleList([
+            VSSBlock(hidden_dim=dim, drop_path=drop_path[i] if isinstance(drop_path, list) else drop_path,
+                     norm_layer=norm_layer, attn_drop_rate=attn_drop, d_state=d_state)
+            for i in range(depth)])
+        _burn_out_proj_rng(self)
+
+    def _run_blocks(self, x):
+        for blk in self.blocks:
+            x = checkpoint.checkpoint(blk, x, use_reentrant=False) if self.use_checkpoint else blk(x)
+        return x
+
+
+class VSSLayer(_Stage):
+    """Encoder stage: `depth` VSSBlocks then an optional PatchMerging2D (mamba_sys.py:588-651)."""
+
+    def __init__(self, dim, depth, attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, downsample=None,
+                 use_checkpoint=False, d_state=16, **kwargs):
+        super().__init__(dim, depth, attn_drop, drop_path, norm_layer, use_checkpoint, d_state)
+        self.downsample = downsample(dim=dim, norm_layer=norm_layer) if downsample is not None else None
+
+    def forward(self, x):
+        x = self._run_blocks(x)
+        return self.downsample(x) if self.downsample is not None else x
+
+
+class VSSLayer_up(_Stage):
+    """Decoder stage: `depth` VSSBlocks then an optional PatchExpand (mamba_sys.py:653-716)."""
+
+    def __init__(self, dim, depth, attn_drop=0.0, drop_path=0.0, norm_layer=nn.LayerNorm, upsample=None,
+                 use_checkpoint=False, d_state=16, **kwargs):
+        super().__init__(dim, depth, attn_drop, drop_path, norm_layer, use_checkpoint, d_state)
+        from .vssm import PatchExpand  # the reference always builds PatchExpand here, whatever `upsample` is
+        self.upsample = PatchExpand(dim, dim_scale=2, norm_layer=nn.LayerNorm) if upsample is not None else None
+
+    def forward(self, x):
+        x = self._run_blocks(x)
+        return self.upsample(x) if self.upsample is not None else x

@@ -1,0 +1,134 @@
+"""autograd wrappers of the CrossScan / CrossMerge / depthwise-conv+SiLU kernels (C ABI: include/ss2d.h).
+
+Reference lines they replace: cross-scan mamba_sys.py:403-404, cross-merge :445-449,
+`act(conv2d(x.permute(0,3,1,2).contiguous()))` :558-559.  GPU tensors only (no CPU path)."""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_F32 = 0
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"{what}: GPU tensor required (mamba_unet_amd has no CPU path)")
+
+
+class _CrossScan(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x, "cross_scan")
+        B, D, H, W = x.shape
+        in_dtype = x.dtype
+        xf = x.float().contiguous()
+        xs = torch.empty((B, 4, D, H * W), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().ss2d_cross_scan_fwd(_F32, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, _stream())
+        _lib.check(rc, "ss2d_cross_scan_fwd")
+        ctx.shape, ctx.in_dtype = (B, D, H, W), in_dtype
+        return xs.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, dxs):
+        B, D, H, W = ctx.shape
+        g = dxs.float().contiguous()
+        dx = torch.empty((B, D, H, W), device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            rc = _lib.load().ss2d_cross_scan_bwd(_F32, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, _stream())
+        _lib.check(rc, "ss2d_cross_scan_bwd")
+        return dx.to(ctx.in_dtype)
+
+
+class _CrossMerge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ys, H, W, channel_last):
+        _need_gpu(ys, "cross_merge")
+        B, K, D, L = ys.shape
+        if K != 4 or L != H * W:
+            raise ValueError(f"cross_merge: expected (B, 4, D, {H * W}), got {tuple(ys.shape)}")
+        in_dtype = ys.dtype
+        yf = ys.float().contiguous()
+        shape = (B, H, W, D) if channel_last else (B, D, L)
+        y = torch.empty(shape, device=ys.device, dtype=torch.float32)
+        with torch.cuda.device(ys.device):
+            rc = _lib.load().ss2d_cross_merge_fwd(_F32, _lib.ptr(yf), _lib.ptr(y), B, D, H, W, int(channel_last), _stream())
+        _lib.check(rc, "ss2d_cross_merge_fwd")
+        ctx.dims, ctx.in_dtype = (B, D, H, W, int(channel_last)), in_dtype
+        return y.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, D, H, W, cl = ctx.dims
+        g = dy.float().contiguous()
+        dys = torch.empty((B, 4, D, H * W), device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            rc = _lib.load().ss2d_cross_merge_bwd(_F32, _lib.ptr(g), _lib.ptr(dys), B, D, H, W, cl, _stream())
+        _lib.check(rc, "ss2d_cross_merge_bwd")
+        return dys.to(ctx.in_dtype), None, None, None
+
+
+class _DwConvSiLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, channel_last_in):
+        _need_gpu(x, "dwconv3x3_silu")
+        in_dtype = x.dtype
+        if channel_last_in:
+            B, H, W, D = x.shape
+            xf = x.float()
+            # accept a channel slice of a wider tensor (the x half of xz): unit channel stride, dense (b,h,w)
+            if not (xf.stride(3) == 1 and xf.stride(1) == W * xf.stride(2) and xf.stride(0) == H * W * xf.stride(2)):
+                xf = xf.contiguous()
+            ldx = xf.stride(2)
+        else:
+            B, D, H, W = x.shape
+            xf = x.float().contiguous()
+            ldx = D
+        if tuple(weight.shape) != (D, 1, 3, 3):
+            raise ValueError(f"dwconv3x3_silu: weight must be ({D}, 1, 3, 3), got {tuple(weight.shape)}")
+        wf = weight.float().contiguous()
+        bf = None if bias is None else bias.float().contiguous()
+        y = torch.empty((B, D, H, W), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().ss2d_dwconv3x3_silu_fwd(_F32, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(y),
+                                                     B, D, H, W, int(channel_last_in), ldx, _stream())
+        _lib.check(rc, "ss2d_dwconv3x3_silu_fwd")
+        ctx.save_for_backward(xf, wf, bf)
+        ctx.meta = (B, D, H, W, int(channel_last_in), ldx, in_dtype, weight.dtype, None if bias is None else bias.dtype)
+        return y.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xf, wf, bf = ctx.saved_tensors
+        B, D, H, W, cl, ldx, in_dtype, w_dtype, b_dtype = ctx.meta
+        g = dy.float().contiguous()
+        dx = torch.empty((B, H, W, D) if cl else (B, D, H, W), device=g.device, dtype=torch.float32)
+        dw = torch.zeros_like(wf)
+        db = torch.zeros_like(bf) if bf is not None else None
+        with torch.cuda.device(g.device):
+            rc = _lib.load().ss2d_dwconv3x3_silu_bwd(_F32, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(g),
+                                                     _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), B, D, H, W, cl, ldx, D,
+                                                     _stream())
+        _lib.check(rc, "ss2d_dwconv3x3_silu_bwd")
+        return dx.to(in_dtype), dw.to(w_dtype), None if db is None else db.to(b_dtype), None
+
+
+def cross_scan(x: torch.Tensor) -> torch.Tensor:
+    """(B, D, H, W) -> (B, 4, D, H*W): row-major, column-major and their reversals (mamba_sys.py:403-404)."""
+    return _CrossScan.apply(x)
+
+
+def cross_merge(ys: torch.Tensor, H: int, W: int, channel_last: bool = True) -> torch.Tensor:
+    """(B, 4, D, H*W) -> (B, H, W, D) (channel_last) or (B, D, H*W): mamba_sys.py:445-449."""
+    return _CrossMerge.apply(ys, H, W, channel_last)
+
+
+def dwconv3x3_silu(x: torch.Tensor, weight: torch.Tensor, bias, channel_last_in: bool = True) -> torch.Tensor:
+    """SiLU(depthwise conv3x3(x) + bias) -> (B, D, H, W).  x is (B, H, W, D) (channel_last_in; may be a
+    channel slice of a wider tensor) or (B, D, H, W).  mamba_sys.py:299-308, :558-559."""
+    return _DwConvSiLU.apply(x, weight, bias, channel_last_in)
