@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- SS2D selective-scan fwd+bwd microbench (BASELINE.json configs[1]) on N MI355X.
+
+A "step" = one forward + one backward pass of the selective scan over one batch of synthetic input
+(B=24, K=4, D=192 -> K*D=768, L=3136, d_state=16, fp32), called through the C ABI of
+libss2d_hip.so with every input already resident in HBM.  The step includes the zero-fill of the
+atomically accumulated gradients (dA, dB, dC, dD, ddelta_bias).
+
+Multi-GPU: the path shards over the batch of slices with no data-path collective, so
+every rank runs its own batch (weak scaling); value = bytes of all ranks / max-over-ranks time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH, K, D, L, N = 24, 4, 192, 3136, 16
+KD = K * D
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(batch):
+    """per call, fp32."""
+    s = 4
+    fwd = s * (3 * batch * KD * L + 2 * batch * K * N * L) + 4 * (KD * N + 2 * KD)
+    bwd = s * (5 * batch * KD * L + 4 * batch * K * N * L) + 4 * 2 * (KD * N + 2 * KD)
+    return fwd, bwd
+
+
+def cpu_baseline():
+    """The reference's CPU path (sequential selective_scan_ref in PyTorch, restated in oracle/) timed
+    on this host: forward + autograd backward on ONE slice (B=1) of the same workload."""
+    from oracle.selective_scan_ref import selective_scan_ref
+    from oracle.ss2d_ref import make_scan_inputs
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    inp = make_scan_inputs(1, KD, L, dstate=N, ngroups=K, seed=0)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+    dout = torch.randn(1, KD, L, generator=torch.Generator().manual_seed(1))
+    t0 = time.perf_counter()
+    y = selective_scan_ref(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"], None,
+                           leaves["delta_bias"], True)
+    y.backward(dout)
+    dt = time.perf_counter() - t0
+    fwd, bwd = algorithmic_bytes(1)
+    return {"value": round((fwd + bwd) / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": f"1 of {BATCH} slices (B=1, K*D={KD}, L={L}, N={N}) fwd + autograd bwd of "
+                      f"oracle.selective_scan_ref, {dt:.2f} s", "seconds": round(dt, 3)}, (inp, y.detach(), leaves)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from mamba_unet_amd import _lib
+    from oracle.ss2d_ref import make_scan_inputs
+    lib = _lib.load()
+    dev = torch.device("cuda", local)
+
+    inp = {k: v.to(dev) for k, v in make_scan_inputs(BATCH, KD, L, dstate=N, ngroups=K, seed=rank).items()}
+    dout = torch.randn(BATCH, KD, L, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    out = torch.empty_like(inp["u"])
+    ckpt = torch.empty(lib.ss2d_scan_ckpt_bytes(BATCH, KD, L, N) // 4, device=dev)
+    du, ddelta = torch.empty_like(out), torch.empty_like(out)
+    # one flat buffer for the atomically accumulated gradients -> a single memset per step
+    sizes = [KD * N, BATCH * K * N * L, BATCH * K * N * L, KD, KD]
+    flat = torch.empty(sum(sizes), device=dev)
+    dA, dB, dC, dD, dbias = torch.split(flat, sizes)
+    P = _lib.ptr
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def fwd():
+        _lib.check(lib.ss2d_selective_scan_fwd(0, P(inp["u"]), P(inp["delta"]), P(inp["A"]), P(inp["B"]), P(inp["C"]),
+                                               P(inp["D"]), None, P(inp["delta_bias"]), P(out), None, P(ckpt),
+                                               BATCH, KD, L, N, K, 1, stream), "fwd")
+
+    def bwd():
+        _lib.check(lib.ss2d_selective_scan_bwd(0, P(inp["u"]), P(inp["delta"]), P(inp["A"]), P(inp["B"]), P(inp["C"]),
+                                               P(inp["D"]), None, P(inp["delta_bias"]), P(dout), P(ckpt), P(du),
+                                               P(ddelta), P(dA), P(dB), P(dC), P(dD), None, P(dbias),
+                                               BATCH, KD, L, N, K, 1, stream), "bwd")
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        fwd()
+        if ev:
+            ev[1].record()
+        flat.zero_()
+        if ev:
+            ev[2].record()
+        bwd()
+        if ev:
+            ev[3].record()
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(evs[i])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    fwd_us = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps * 1e3
+    bwd_us = sum(e[2].elapsed_time(e[3]) for e in evs) / args.steps * 1e3
+    fb, bb = algorithmic_bytes(BATCH)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * (fb + bb) / (elapsed / args.steps) / 1e9
+
+    if rank == 0:
+        # parity spot check of what was just timed (slice 0) + CPU baseline, N=1 only
+        cpu = None
+        parity = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu, (cinp, cy, leaves) = cpu_baseline()
+            from mamba_unet_amd import selective_scan_fn
+            gi = {k: v.to(dev).requires_grad_(True) for k, v in cinp.items()}
+            gy = selective_scan_fn(gi["u"], gi["delta"], gi["A"], gi["B"], gi["C"], gi["D"], None, gi["delta_bias"], True)
+            gdout = torch.randn(1, KD, L, generator=torch.Generator().manual_seed(1))
+            gy.backward(gdout.to(dev))
+            rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())  # noqa: E731
+            parity = {"out": rel(gy.detach(), cy), **{"d" + k: rel(gi[k].grad, leaves[k].grad) for k in gi}}
+        dominant_us, dominant_bytes, dominant = (bwd_us, bb, "scan_bwd_f32_kernel") if bwd_us >= fwd_us else (fwd_us, fb, "scan_fwd_f32_kernel")
+        achieved = dominant_bytes / (dominant_us * 1e-6) / 1e9
+        line = {
+            "metric": "SS2D selective-scan fwd+bwd achieved HBM GB/s (algorithmic bytes / time)",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: SS2D selective-scan microbench B=24 K=4 D=192 L=3136 "
+                                   "d_state=16 fp32 fwd+bwd per GPU", "batch_per_gpu": BATCH, "KD": KD, "L": L,
+                       "d_state": N, "parallelism": f"batch-sharded x{world}, no collective"},
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": dominant_bytes, "avg_launch_us": round(dominant_us, 2)},
+            "frac_of_hbm_peak_fwd_bwd": round(value / world / HBM_PEAK_GBS, 4),
+            "kernels_us": {"scan_fwd": round(fwd_us, 2), "scan_bwd": round(bwd_us, 2),
+                           "fwd_GBs": round(fb / fwd_us / 1e3, 1), "bwd_GBs": round(bb / bwd_us / 1e3, 1)},
+            "cpu_baseline": cpu, "parity_rel_l2_vs_cpu_oracle": parity,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

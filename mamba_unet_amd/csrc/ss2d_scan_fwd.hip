@@ -45,7 +45,8 @@ __device__ __forceinline__ void row_scan_pair(float &hx, float &hy, float &ax, f
 #undef SS2D_STEP
 }
 
-template <int NW, bool HAS_Z, bool VEC4>
+// FULL: dstate == 16 known at compile time (the only value Mamba-UNet uses): no per-pair bounds checks
+template <int NW, bool HAS_Z, bool VEC4, bool FULL>
 __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdParams p) {
     // [buffer][B|C][(pair*4 + quarter)*16 + seg] ; one f4 = (n,t),(n+1,t),(n,t+1),(n+1,t+1)
     __shared__ f4 tile[2][2][NP * 4 * 16];
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
     const int c_in_g = cb * (NW * 4) + wave * 4 + row;
     const bool row_ok = c_in_g < p.dpg;
     const int c = g * p.dpg + (row_ok ? c_in_g : 0);
-    const int L = p.L, N = p.N;
+    const int L = p.L, N = FULL ? 16 : p.N;
 
     const size_t rowoff = ((size_t)b * p.dim + c) * (size_t)L;
     const float *__restrict__ urow = p.u + rowoff;
@@ -131,14 +132,23 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
 
         __syncthreads();  // tile[buf] complete; the other buffer is free for the next chunk's staging
 
-        float *ck = p.ckpt ? p.ckpt + (((size_t)b * p.dim + c) * p.nchunks + chunk) * N : nullptr;
+        if (p.ckpt != nullptr && seg == 0 && row_ok) {  // state entering this chunk, for the backward
+            float *ck = p.ckpt + (((size_t)b * p.dim + c) * p.nchunks + chunk) * N;
+            if (FULL) {
 #pragma unroll
-        for (int np = 0; np < NP; ++np) {
-            if (2 * np < N) {  // wave-uniform
-                if (ck != nullptr && seg == 0 && row_ok) {
-                    ck[2 * np] = carry[np].x;
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<f4 *>(ck + 4 * q) = f4{carry[2 * q].x, carry[2 * q].y, carry[2 * q + 1].x, carry[2 * q + 1].y};
+            } else {
+#pragma unroll
+                for (int np = 0; np < NP; ++np) {
+                    if (2 * np < N) ck[2 * np] = carry[np].x;
                     if (2 * np + 1 < N) ck[2 * np + 1] = carry[np].y;
                 }
+            }
+        }
+#pragma unroll
+        for (int np = 0; np < NP; ++np) {
+            if (FULL || 2 * np < N) {  // wave-uniform
                 f2 a[T], bb[T];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -169,6 +179,12 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
                 }
                 carry[np].x = dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, h.x);
                 carry[np].y = dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, h.y);
+                // Pin the partial outputs here: otherwise LLVM sinks the whole y accumulation into the
+                // (conditional) store block at the end of the chunk and keeps every C and h value of all 8
+                // state pairs alive (256 VGPRs + AGPR spills).  Also keeps the pairs from being interleaved.
+#pragma unroll
+                for (int t = 0; t < T; ++t) asm volatile("" : "+v"(y2[t]));
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         float yv[T];
@@ -194,12 +210,15 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
 template <int NW>
 int launch_fwd(const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
     dim3 grid(p.nwg), block(NW * 64);
+    const bool full = p.N == 16;
     if (has_z) {
-        if (vec4) hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, true, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, true, false>), grid, block, 0, s, p);
+        if (vec4) hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, true, true, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, true, false, false>), grid, block, 0, s, p);
+    } else if (vec4 && full) {
+        hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, true, true>), grid, block, 0, s, p);  // the SS2D call pattern
     } else {
-        if (vec4) hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, true>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, false>), grid, block, 0, s, p);
+        if (vec4) hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, true, false>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, false, false>), grid, block, 0, s, p);
     }
     return (int)hipGetLastError();
 }
