@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 BATCH, K, D, L, N = 24, 4, 192, 3136, 16
 KD = K * D
+CPU_SLICES = 12         # bounded CPU sample: ~10-30 s of host time
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -45,17 +46,18 @@ def cpu_baseline():
     from oracle.ss2d_ref import make_scan_inputs
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    inp = make_scan_inputs(1, KD, L, dstate=N, ngroups=K, seed=0)
+    nb = CPU_SLICES
+    inp = make_scan_inputs(nb, KD, L, dstate=N, ngroups=K, seed=0)
     leaves = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
-    dout = torch.randn(1, KD, L, generator=torch.Generator().manual_seed(1))
+    dout = torch.randn(nb, KD, L, generator=torch.Generator().manual_seed(1))
     t0 = time.perf_counter()
     y = selective_scan_ref(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"], None,
                            leaves["delta_bias"], True)
     y.backward(dout)
     dt = time.perf_counter() - t0
-    fwd, bwd = algorithmic_bytes(1)
+    fwd, bwd = algorithmic_bytes(nb)
     return {"value": round((fwd + bwd) / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": f"1 of {BATCH} slices (B=1, K*D={KD}, L={L}, N={N}) fwd + autograd bwd of "
+            "sample": f"{nb} of {BATCH} slices (B={nb}, K*D={KD}, L={L}, N={N}) fwd + autograd bwd of "
                       f"oracle.selective_scan_ref, {dt:.2f} s", "seconds": round(dt, 3)}, (inp, y.detach(), leaves)
 
 
@@ -151,7 +153,7 @@ def main():
             from mamba_unet_amd import selective_scan_fn
             gi = {k: v.to(dev).requires_grad_(True) for k, v in cinp.items()}
             gy = selective_scan_fn(gi["u"], gi["delta"], gi["A"], gi["B"], gi["C"], gi["D"], None, gi["delta_bias"], True)
-            gdout = torch.randn(1, KD, L, generator=torch.Generator().manual_seed(1))
+            gdout = torch.randn(CPU_SLICES, KD, L, generator=torch.Generator().manual_seed(1))
             gy.backward(gdout.to(dev))
             rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())  # noqa: E731
             parity = {"out": rel(gy.detach(), cy), **{"d" + k: rel(gi[k].grad, leaves[k].grad) for k in gi}}
