@@ -13,6 +13,7 @@
 //     float atomic per element and chunk;
 //   * dA/dD/ddelta_bias are reduced over lanes (DPP row sums), over chunks (LDS / registers) and
 //     over batch (global float atomics at the end).
+#include <cstdlib>
 #include "ss2d_common.h"
 #include "../../include/ss2d.h"
 
@@ -70,12 +71,18 @@ __device__ __forceinline__ float row_sum_to_lane15(float v) {
 // even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the
 // second; each swap is followed by one add (1.5 VALU ops per value instead of an LDS float atomic,
 // which runs ~3 cycles PER LANE on gfx950).
-__device__ __forceinline__ float rows_reduce4(float x0, float x1, float x2, float x3) {
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
-                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3));
-    float s01 = x0 + x1, s23 = x2 + x3;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(s01), "+v"(s23));
-    return s01 + s23;
+__device__ __forceinline__ void rows_reduce4x2(float &x0, float x1, float x2, float x3, float &y0, float y1, float y2, float y3) {
+    // two independent 4-value reductions in one block: fewer hazard nops (x0 / y0 receive the results)
+    asm volatile("s_nop 1\n\t"
+                 "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
+                 "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32 %0, %0, %1\n\tv_add_f32 %2, %2, %3\n\tv_add_f32 %4, %4, %5\n\tv_add_f32 %6, %6, %7\n\t"
+                 "s_nop 1\n\t"
+                 "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %4, %6\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32 %0, %0, %2\n\tv_add_f32 %4, %4, %6\n\t"
+                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
 }
 
 template <int NW, bool HAS_Z, bool VEC4>
@@ -275,9 +282,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
                         dBprev = dBc; dCprev = dCc;
                     } else {
                         // channel sum over the 4 rows for items (t+1, t) x 2 states; row r = (item t+1-(r>>1), state r&1)
-#if !defined(SS2D_ABLATE_LDSADD)
-                        const float sB = rows_reduce4(dBprev.x, dBprev.y, dBc.x, dBc.y);
-                        const float sC = rows_reduce4(dCprev.x, dCprev.y, dCc.x, dCc.y);
+#if !defined(SS2D_ABLATE_LDSADD) && !defined(SS2D_ABLATE_BFLY)
+                        float sB = dBprev.x, sC = dCprev.x;
+                        rows_reduce4x2(sB, dBprev.y, dBc.x, dBc.y, sC, dCprev.y, dCc.x, dCc.y);
                         float *aB = accw + ((np * 2 + 0) * 4 + (t >> 1)) * 64;
                         float *aC = accw + ((np * 2 + 1) * 4 + (t >> 1)) * 64;
                         *aB += sB;
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
         }
         __syncthreads();
         // ---- flush dB/dC of this chunk: add the 4 row tiles, one global atomic per element
+#if !defined(SS2D_ABLATE_FLUSHALL)
         for (int idx = tid; idx < 2 * 16 * CHUNK; idx += NW * 64) {
             const int mat = idx >> 11, n = (idx >> 7) & 15, pos = idx & 127;
             const int np = n >> 1, s = n & 1, sgm = pos >> 3, t = pos & 7;
@@ -335,6 +343,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
             asm volatile("" ::"v"(v));
 #endif
         }
+#endif
     }
     __syncthreads();
     // ---- dA / dD / ddelta_bias: sums over batch -> global atomics
@@ -396,6 +405,10 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
         const long long units = (long long)batch * ngroups;
         rounds = 3;
         while (rounds > 1 && units * ((p.dpg + per_round * rounds - 1) / (per_round * rounds)) < 192) --rounds;
+    }
+    if (const char *e = getenv("SS2D_BWD_ROUNDS")) {  // tuning knob for experiments; 1..3
+        const int r = atoi(e);
+        if (r >= 1 && r <= 3) rounds = r;
     }
     p.rounds = rounds; p.cb = per_round * rounds;
     p.wgs_per_group = (p.dpg + p.cb - 1) / p.cb;
