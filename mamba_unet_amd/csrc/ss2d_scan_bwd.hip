@@ -106,7 +106,6 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
     float *__restrict__ dCg = p.dC + (size_t)(b * p.G + g) * N * (size_t)L;
 
     // zero the LDS accumulators / carries
-    for (int i = tid; i < NW * ACC_WAVE_FLOATS; i += NW * 64) acc[i] = 0.0f;
     for (int i = tid; i < NW * p.rounds * NP * 4; i += NW * 64) rc[i] = f2{0.0f, 0.0f};
     for (int i = tid; i < NW * p.rounds * (64 + 8); i += NW * 64) dAs[i] = 0.0f;  // dAs and dXs are contiguous
 
@@ -168,7 +167,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
             }
             const float *ck = p.ckpt + (((size_t)b * p.dim + c) * p.nchunks + chunk) * N;
             const float *Arow = p.A + (size_t)c * N;
-            float *accw = acc + wave * ACC_WAVE_FLOATS + lane;  // private to this wave: plain read-modify-write
+            // Private (per wave) dB/dC tile, plain read-modify-write.  Within a (pair, matrix) block of 256
+            // floats the slot of (item pair j, row -> (state s, odd/even item hi), seg) is bit-swizzled so that
+            // BOTH this per-lane access (lanes = 16 segs x rows) and the flush (lanes = consecutive positions)
+            // hit 32 distinct banks:  low5 = seg[1:0] | (seg2^j1)<<2 | (seg3^j0)<<3 | (s^hi)<<4 ; j0<<5 | hi<<6 | j1<<7
+            const int lane_base = seg | ((((row & 1) ^ (row >> 1)) & 1) << 4) | ((row >> 1) << 6);
+            float *accw = acc + wave * ACC_WAVE_FLOATS;
 
             float zs[T], zv[T];  // silu(z) and z when gated
             if (HAS_Z) {
@@ -285,10 +289,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
 #if !defined(SS2D_ABLATE_LDSADD) && !defined(SS2D_ABLATE_BFLY)
                         float sB = dBprev.x, sC = dCprev.x;
                         rows_reduce4x2(sB, dBprev.y, dBc.x, dBc.y, sC, dCprev.y, dCc.x, dCc.y);
-                        float *aB = accw + ((np * 2 + 0) * 4 + (t >> 1)) * 64;
-                        float *aC = accw + ((np * 2 + 1) * 4 + (t >> 1)) * 64;
-                        *aB += sB;
-                        *aC += sC;
+                        const int j = t >> 1;
+                        const int off = (lane_base ^ ((j >> 1) << 2) ^ ((j & 1) << 3)) + ((j & 1) << 5) + ((j >> 1) << 7);
+                        float *aB = accw + (np * 2 + 0) * 256 + off;
+                        float *aC = accw + (np * 2 + 1) * 256 + off;
+                        if (r == 0) { *aB = sB; *aC = sC; }   // first round of the chunk overwrites: no zero-fill pass
+                        else { *aB += sB; *aC += sC; }
 #else
                         asm volatile("" ::"v"(dBc.x), "v"(dBc.y), "v"(dCc.x), "v"(dCc.y), "v"(dBprev.x), "v"(dCprev.x));
 #endif
@@ -332,11 +338,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
         for (int idx = tid; idx < 2 * 16 * CHUNK; idx += NW * 64) {
             const int mat = idx >> 11, n = (idx >> 7) & 15, pos = idx & 127;
             const int np = n >> 1, s = n & 1, sgm = pos >> 3, t = pos & 7;
-            const int rw = ((t & 1) ? 0 : 2) + s;
-            const int off = ((np * 2 + mat) * 4 + (t >> 1)) * 64 + rw * 16 + sgm;
+            const int j = t >> 1, hi = (t & 1) ^ 1;
+            const int off = (np * 2 + mat) * 256 + ((sgm & 3) | ((((sgm >> 2) & 1) ^ (j >> 1)) << 2) | ((((sgm >> 3) & 1) ^ (j & 1)) << 3) |
+                                                   ((s ^ hi) << 4) | ((j & 1) << 5) | (hi << 6) | ((j >> 1) << 7));
             float v = 0.0f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) { v += acc[w * ACC_WAVE_FLOATS + off]; acc[w * ACC_WAVE_FLOATS + off] = 0.0f; }
+            for (int w = 0; w < NW; ++w) v += acc[w * ACC_WAVE_FLOATS + off];
 #if !defined(SS2D_ABLATE_FLUSH)
             if (n < N && base + pos < L) atomicAdd((mat ? dCg : dBg) + (size_t)n * L + base + pos, v);
 #else

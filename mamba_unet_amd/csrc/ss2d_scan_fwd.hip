@@ -80,6 +80,11 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
     const float Dc = p.D ? p.D[c] : 0.0f;
     const float bias = p.bias ? p.bias[c] : 0.0f;
 
+    // software prefetch: the next chunk's u / delta are requested before the current chunk is computed
+    float un[T], dn[T];
+    load8<VEC4>(urow, seg * T, L, row_ok, un);
+    load8<VEC4>(drow, seg * T, L, row_ok, dn);
+
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int buf = chunk & 1;
         const int base = chunk * CHUNK;
@@ -114,8 +119,12 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
         // ---- this lane's 8 positions of u / delta
         const int p0 = base + seg * T;
         float uv[T], dt[T], du[T];
-        load8<VEC4>(urow, p0, L, row_ok, uv);
-        load8<VEC4>(drow, p0, L, row_ok, dt);
+#pragma unroll
+        for (int t = 0; t < T; ++t) { uv[t] = un[t]; dt[t] = dn[t]; }
+        if (chunk + 1 < p.nchunks) {
+            load8<VEC4>(urow, p0 + CHUNK, L, row_ok, un);
+            load8<VEC4>(drow, p0 + CHUNK, L, row_ok, dn);
+        }
         float S = 0.0f;
 #pragma unroll
         for (int t = 0; t < T; ++t) {
