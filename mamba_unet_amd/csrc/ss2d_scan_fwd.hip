@@ -13,6 +13,7 @@
 // chunk's B/C tile once in LDS, interleaving state pairs so one ds_read_b128 feeds two packed FMAs.
 // The product of exp(delta*A) over a lane's items is exp(A * sum(delta)), so the lane aggregate costs
 // one exp instead of seven multiplies.
+#include <cstdlib>
 #include "ss2d_common.h"
 #include "../../include/ss2d.h"
 
@@ -254,7 +255,8 @@ extern "C" int ss2d_selective_scan_fwd(int dtype, const void *u, const void *del
     p.D = D; p.z = (const float *)z; p.bias = delta_bias; p.out = (float *)out; p.last = last_state; p.ckpt = ckpt;
     p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
     p.nchunks = ss2d_scan_num_chunks(L); p.softplus = delta_softplus;
-    const int nw = p.dpg >= 16 ? 4 : (p.dpg >= 8 ? 2 : 1);
+    int nw = p.dpg >= 16 ? 4 : (p.dpg >= 8 ? 2 : 1);
+    if (const char *e = getenv("SS2D_FWD_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; }  // tuning knob
     p.wgs_per_group = (p.dpg + nw * 4 - 1) / (nw * 4);
     const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
     if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_fwd: grid too large"); return -6; }
