@@ -29,6 +29,11 @@ BATCH, K, D, L, N = 24, 4, 192, 3136, 16
 KD = K * D
 CPU_SLICES = 12         # bounded CPU sample: ~10-30 s of host time
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# HBM bytes per launch from the PMC counters (cannot be collected inside this process): separate rocprofv3 --pmc
+# passes of this very command, 2 x FETCH_SIZE x 1024 (gfx950 tallies a 128-byte read request as 64 bytes) +
+# WRITE_SIZE x 1024, averaged over the dispatches -- tools/profile_round.sh, profiles/r01/bench_pmc_summary_final.txt.
+# Valid for the config-2 shapes of this file only; re-measure when a kernel's memory behaviour changes.
+PMC_TRAFFIC_BYTES = {"scan_fwd_f32_kernel": 776671024, "scan_bwd_f32_kernel": 1337586368}
 
 
 def algorithmic_bytes(batch):
@@ -168,7 +173,8 @@ def main():
                                    "d_state=16 fp32 fwd+bwd per GPU", "batch_per_gpu": BATCH, "KD": KD, "L": L,
                        "d_state": N, "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES.get(dominant),
+                         "traffic_source": "rocprofv3 --pmc passes recorded in profiles/r01/bench_pmc_summary_final.txt",
                          "algorithmic_bytes_per_launch": dominant_bytes, "avg_launch_us": round(dominant_us, 2)},
             "frac_of_hbm_peak_fwd_bwd": round(value / world / HBM_PEAK_GBS, 4),
             "kernels_us": {"scan_fwd": round(fwd_us, 2), "scan_bwd": round(bwd_us, 2),
