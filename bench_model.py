@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""bench_model.py -- MambaUNet slices/s (BASELINE.json configs[2], [3], [4]; SURVEY.md 8d "Configs 3/5 inputs").
+
+The second half of BASELINE.json's metric: a caller-level measurement of the hot path inside the whole
+network.  bench.py stays the headline (scan GB/s on configs[1]); this file reports
+
+    --mode train   full training step of train_fully_supervised_2D_VIM.py:150-164
+                   (fwd, softmax, 0.5*(CE+Dice), zero_grad, backward, SGD step, poly LR)
+    --mode infer   eval-mode forward under no_grad
+    --mode semi    dual-network cross pseudo supervision + ConstraLoss (train_Semi_Mamba_UNet.py:411-456)
+
+on synthetic slices (`rand(B,1,S,S)`, `randint` labels), seed 1337, random init (no checkpoint offline).
+One process per GPU; under torch.distributed.run the model is wrapped in DDP (RCCL all-reduce of the
+76.5 MB gradient overlapped with backward), batch 24 per GPU (weak scaling).
+
+    python bench_model.py [--mode train] [--size 224] [--classes 4] [--batch 24] [--dtype fp32|bf16]
+                          [--gpus N] [--steps K] [--warmup W]
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", choices=["train", "infer", "semi"], default="train")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--classes", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=24, help="slices per GPU")
+    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mamba_unet_amd import MambaUnet
+    from mamba_unet_amd.dist import wrap_ddp
+    from mamba_unet_amd.train import make_sgd, semi_step, supervised_step
+
+    bf16 = args.dtype == "bf16"
+    torch.manual_seed(1337)                       # train_fully_supervised_2D_VIM.py:243-246
+    nets = [MambaUnet(img_size=args.size, num_classes=args.classes).to(dev) for _ in range(2 if args.mode == "semi" else 1)]
+    n_params = sum(p.numel() for p in nets[0].parameters())
+    torch.manual_seed(1337 + rank)                # per-rank data and DropPath streams
+    images = torch.rand(args.batch, 1, args.size, args.size, device=dev)
+    labels = torch.randint(0, args.classes, (args.batch, args.size, args.size), device=dev, dtype=torch.uint8)
+    max_it = 10000
+
+    if args.mode == "infer":
+        net = nets[0].eval()
+
+        def step(it):
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+                return net(images)
+    elif args.mode == "train":
+        net = wrap_ddp(nets[0].train(), local)
+        opt = make_sgd(net.parameters())
+
+        def step(it):
+            return supervised_step(net, opt, images, labels, args.classes, it, max_it, autocast_bf16=bf16)
+    else:
+        n1, n2 = (wrap_ddp(n.train(), local) for n in nets)
+        o1, o2 = make_sgd(n1.parameters()), make_sgd(n2.parameters())
+
+        def step(it):
+            return semi_step(n1, n2, o1, o2, images, labels, args.batch // 2, args.classes, it, max_it, 0.1)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for it in range(args.warmup):
+        step(it)
+    sync_all()
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        last = step(args.warmup + it)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(last.float()).all())
+
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"MambaUNet {args.mode} slices/s @{args.size}x{args.size}",
+            "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "slices/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 autocast, fp32 scan + master weights" if bf16 else "f32", "data": "synthetic",
+            "config": {"workload": f"MambaUNet (VSSM tiny, depths 2-2-2-2, {n_params} params) {args.mode}, batch "
+                                   f"{args.batch} per GPU, {args.size}x{args.size}, {args.classes} classes",
+                       "parallelism": f"DDP x{world} (batch-sharded slices, RCCL gradient all-reduce)"},
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "finite": finite}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

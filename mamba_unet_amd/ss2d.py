@@ -122,9 +122,11 @@ class SS2D(nn.Module):
         B, D, H, W = x.shape
         L, K, N, R = H * W, 4, self.d_state, self.dt_rank
         xs = cross_scan(x)                                                        # (B, 4, D, L)
-        x_dbl = torch.einsum("bkdl,kcd->bkcl", xs, self.x_proj_weight)
+        # the two einsums of :407/:420 as broadcast batched GEMMs on the tensors where they lie: einsum would
+        # first copy xs (the 231 MB tensor) into a (k, b, l, d) layout and permute the results back
+        x_dbl = torch.matmul(self.x_proj_weight.unsqueeze(0), xs)                 # (B, K, R+2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
-        dts = torch.einsum("bkrl,kdr->bkdl", dts, self.dt_projs_weight)
+        dts = torch.matmul(self.dt_projs_weight.unsqueeze(0), dts)               # (B, K, D, L)
         out_y = selective_scan_fn(
             xs.float().reshape(B, K * D, L), dts.float().reshape(B, K * D, L),
             -torch.exp(self.A_logs.float()).view(K * D, N),
