@@ -35,7 +35,8 @@ def main():
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=4)
     ap.add_argument("--batch", type=int, default=24, help="slices per GPU")
-    ap.add_argument("--dtype", choices=["fp32", "bf16"], default="fp32")
+    ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16-fp32scan"], default="fp32",
+                    help="bf16: autocast + bf16 kernel I/O; bf16-fp32scan: autocast with the reference's fp32 casts around the scan")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -55,7 +56,9 @@ def main():
     from mamba_unet_amd.dist import wrap_ddp
     from mamba_unet_amd.train import make_sgd, semi_step, supervised_step
 
-    bf16 = args.dtype == "bf16"
+    bf16 = args.dtype != "fp32"
+    from mamba_unet_amd import SS2D
+    SS2D.bf16_scan_io = args.dtype == "bf16"
     torch.manual_seed(1337)                       # train_fully_supervised_2D_VIM.py:243-246
     nets = [MambaUnet(img_size=args.size, num_classes=args.classes).to(dev) for _ in range(2 if args.mode == "semi" else 1)]
     n_params = sum(p.numel() for p in nets[0].parameters())
@@ -108,7 +111,8 @@ def main():
             "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "slices/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16 autocast, fp32 scan + master weights" if bf16 else "f32", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16 autocast + bf16 kernel I/O (fp32 scan arithmetic/state, fp32 master weights)",
+                      "bf16-fp32scan": "bf16 autocast, fp32 scan I/O, fp32 master weights"}[args.dtype], "data": "synthetic",
             "config": {"workload": f"MambaUNet (VSSM tiny, depths 2-2-2-2, {n_params} params) {args.mode}, batch "
                                    f"{args.batch} per GPU, {args.size}x{args.size}, {args.classes} classes",
                        "parallelism": f"DDP x{world} (batch-sharded slices, RCCL gradient all-reduce)"},

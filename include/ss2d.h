@@ -24,7 +24,10 @@ extern "C" {
 
 #define SS2D_ABI_VERSION 1
 #define SS2D_DTYPE_F32 0
-#define SS2D_DTYPE_BF16 1   /* u, delta, B, C, z, out and their grads in bf16; params and state fp32 */
+#define SS2D_DTYPE_BF16 1   /* every `void *` tensor (activations and their gradients) is stored as bf16; arithmetic,
+                               parameters (`float *`), scan state/checkpoints and the atomically accumulated
+                               gradients (dA, dB, dC, dD, ddelta_bias, dw, dbias) stay fp32; vector path needs
+                               8-byte aligned pointers and L % 4 == 0, otherwise a scalar path is used */
 #define SS2D_SCAN_CHUNK 128 /* positions per state checkpoint */
 #define SS2D_MAX_DSTATE 16
 

@@ -51,28 +51,43 @@ __device__ __forceinline__ int xcd_remap(int orig, int nwg) {
     return base + (orig >> 3);
 }
 
-// 8 consecutive floats per lane, zero-filled past `L`.  VEC4 needs (row base + p0) 16-byte aligned and L % 4 == 0.
-template <bool VEC4>
-__device__ __forceinline__ void load8(const float *__restrict__ row, int p0, int L, bool ok, float (&v)[8]) {
+// ---- element I/O in the two storage types of the ABI (fp32, bf16); arithmetic is always fp32.
+// bf16 -> fp32 is a shift, fp32 -> bf16 is v_cvt_pk_bf16_f32 (round to nearest even) on gfx950.
+typedef __bf16 bf16;
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float ld1(const float *p) { return *p; }
+__device__ __forceinline__ float ld1(const bf16 *p) { return (float)*p; }
+__device__ __forceinline__ void st1(float *p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bf16 *p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ f4 ld4(const bf16 *p) { return __builtin_convertvector(*reinterpret_cast<const bf16x4 *>(p), f4); }
+__device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+__device__ __forceinline__ void st4(bf16 *p, f4 v) { *reinterpret_cast<bf16x4 *>(p) = __builtin_convertvector(v, bf16x4); }
+
+// 8 consecutive elements per lane, zero-filled past `L`.  VEC4 needs L % 4 == 0 and a base pointer aligned to
+// 4 elements (16 bytes for fp32, 8 bytes for bf16).
+template <bool VEC4, typename IO>
+__device__ __forceinline__ void load8(const IO *__restrict__ row, int p0, int L, bool ok, float (&v)[8]) {
     if (VEC4) {
         f4 a = f4{0, 0, 0, 0}, b = f4{0, 0, 0, 0};
-        if (ok && p0 < L) a = *reinterpret_cast<const f4 *>(row + p0);
-        if (ok && p0 + 4 < L) b = *reinterpret_cast<const f4 *>(row + p0 + 4);
+        if (ok && p0 < L) a = ld4(row + p0);
+        if (ok && p0 + 4 < L) b = ld4(row + p0 + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) v[t] = (ok && p0 + t < L) ? row[p0 + t] : 0.0f;
+        for (int t = 0; t < 8; ++t) v[t] = (ok && p0 + t < L) ? ld1(row + p0 + t) : 0.0f;
     }
 }
-template <bool VEC4>
-__device__ __forceinline__ void store8(float *__restrict__ row, int p0, int L, bool ok, const float (&v)[8]) {
+template <bool VEC4, typename IO>
+__device__ __forceinline__ void store8(IO *__restrict__ row, int p0, int L, bool ok, const float (&v)[8]) {
     if (VEC4) {
-        if (ok && p0 < L) *reinterpret_cast<f4 *>(row + p0) = f4{v[0], v[1], v[2], v[3]};
-        if (ok && p0 + 4 < L) *reinterpret_cast<f4 *>(row + p0 + 4) = f4{v[4], v[5], v[6], v[7]};
+        if (ok && p0 < L) st4(row + p0, f4{v[0], v[1], v[2], v[3]});
+        if (ok && p0 + 4 < L) st4(row + p0 + 4, f4{v[4], v[5], v[6], v[7]});
     } else {
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            if (ok && p0 + t < L) row[p0 + t] = v[t];
+            if (ok && p0 + t < L) st1(row + p0 + t, v[t]);
     }
 }
 

@@ -17,8 +17,8 @@ constexpr int SW = TW + 1;              // padded w stride
 constexpr int SD = TH * SW + 1;         // padded channel stride (odd -> conflict-free channel-fast access)
 
 struct CrossParams {
-    const float *in;   // scan: x ; merge: ys
-    float *out;        // scan: xs; merge: y
+    const void *in;    // scan: x ; merge: ys   (IO type: fp32 or bf16)
+    void *out;         // scan: xs; merge: y
     int B, D, H, W, tiles_h, tiles_w, tiles_d;
 };
 
@@ -31,9 +31,11 @@ __device__ __forceinline__ void tile_coords(const CrossParams &p, int &b, int &d
 }
 
 // x side is channel-last (B,H,W,D) when CL, else (B,D,H,W)
-template <bool CL>
+template <bool CL, typename IO>
 __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
     __shared__ float s[TD * SD];
+    const IO *__restrict__ in = static_cast<const IO *>(p.in);
+    IO *__restrict__ out = static_cast<IO *>(p.out);
     int b, d0, h0, w0;
     tile_coords(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
@@ -42,14 +44,14 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
         for (int i = tid; i < TD * TH * TW; i += 256) {
             const int d = i & (TD - 1), pos = i >> 5, w = pos & (TW - 1), h = pos >> 4;
             float v = 0.0f;
-            if (d0 + d < D && h0 + h < H && w0 + w < W) v = p.in[(((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d];
+            if (d0 + d < D && h0 + h < H && w0 + w < W) v = ld1(in + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d);
             s[d * SD + h * SW + w] = v;
         }
     } else {
         for (int i = tid; i < TD * TH * TW; i += 256) {
             const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
             float v = 0.0f;
-            if (d0 + d < D && h0 + h < H && w0 + w < W) v = p.in[(((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w];
+            if (d0 + d < D && h0 + h < H && w0 + w < W) v = ld1(in + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w);
             s[d * SD + h * SW + w] = v;
         }
     }
@@ -60,10 +62,10 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const float v = s[d * SD + h * SW + w];
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            float *o0 = p.out + (((size_t)b * 4 + 0) * D + d0 + d) * L;
-            float *o2 = p.out + (((size_t)b * 4 + 2) * D + d0 + d) * L;
-            o0[pp] = v;
-            o2[L - 1 - pp] = v;
+            IO *o0 = out + (((size_t)b * 4 + 0) * D + d0 + d) * L;
+            IO *o2 = out + (((size_t)b * 4 + 2) * D + d0 + d) * L;
+            st1(o0 + pp, v);
+            st1(o2 + (L - 1 - pp), v);
         }
     }
     // column-major directions 1 and 3: h on the fast lanes
@@ -72,17 +74,20 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const float v = s[d * SD + h * SW + w];
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            float *o1 = p.out + (((size_t)b * 4 + 1) * D + d0 + d) * L;
-            float *o3 = p.out + (((size_t)b * 4 + 3) * D + d0 + d) * L;
-            o1[q] = v;
-            o3[L - 1 - q] = v;
+            IO *o1 = out + (((size_t)b * 4 + 1) * D + d0 + d) * L;
+            IO *o3 = out + (((size_t)b * 4 + 3) * D + d0 + d) * L;
+            st1(o1 + q, v);
+            st1(o3 + (L - 1 - q), v);
         }
     }
 }
 
-template <bool CL>
+// sums in fp32 (LDS), one rounding at the end for bf16 output
+template <bool CL, typename IO>
 __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
     __shared__ float s[TD * SD];
+    const IO *__restrict__ in = static_cast<const IO *>(p.in);
+    IO *__restrict__ out = static_cast<IO *>(p.out);
     int b, d0, h0, w0;
     tile_coords(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
@@ -92,9 +97,9 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
         float v = 0.0f;
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            const float *i0 = p.in + (((size_t)b * 4 + 0) * D + d0 + d) * L;
-            const float *i2 = p.in + (((size_t)b * 4 + 2) * D + d0 + d) * L;
-            v = i0[pp] + i2[L - 1 - pp];
+            const IO *i0 = in + (((size_t)b * 4 + 0) * D + d0 + d) * L;
+            const IO *i2 = in + (((size_t)b * 4 + 2) * D + d0 + d) * L;
+            v = ld1(i0 + pp) + ld1(i2 + (L - 1 - pp));
         }
         s[d * SD + h * SW + w] = v;
     }
@@ -103,10 +108,10 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
         const int h = i & (TH - 1), w = (i >> 4) & (TW - 1), d = i >> 8;
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            const float *i1 = p.in + (((size_t)b * 4 + 1) * D + d0 + d) * L;
-            const float *i3 = p.in + (((size_t)b * 4 + 3) * D + d0 + d) * L;
+            const IO *i1 = in + (((size_t)b * 4 + 1) * D + d0 + d) * L;
+            const IO *i3 = in + (((size_t)b * 4 + 3) * D + d0 + d) * L;
             // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
-            s[d * SD + h * SW + w] = (s[d * SD + h * SW + w] + i1[q]) + i3[L - 1 - q];
+            s[d * SD + h * SW + w] = (s[d * SD + h * SW + w] + ld1(i1 + q)) + ld1(i3 + (L - 1 - q));
         }
     }
     __syncthreads();
@@ -114,33 +119,35 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
         for (int i = tid; i < TD * TH * TW; i += 256) {
             const int d = i & (TD - 1), pos = i >> 5, w = pos & (TW - 1), h = pos >> 4;
             if (d0 + d < D && h0 + h < H && w0 + w < W)
-                p.out[(((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d] = s[d * SD + h * SW + w];
+                st1(out + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d, s[d * SD + h * SW + w]);
         }
     } else {
         for (int i = tid; i < TD * TH * TW; i += 256) {
             const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
             if (d0 + d < D && h0 + h < H && w0 + w < W)
-                p.out[(((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w] = s[d * SD + h * SW + w];
+                st1(out + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w, s[d * SD + h * SW + w]);
         }
     }
 }
 
 int run(bool merge, bool cl, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name) {
-    if (dtype != SS2D_DTYPE_F32) { ss2d_set_error("%s: dtype %d not supported (fp32 only)", name, dtype); return -1; }
+    if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("%s: unknown dtype %d", name, dtype); return -1; }
     if (!in || !out) { ss2d_set_error("%s: null pointer", name); return -2; }
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
     CrossParams p;
-    p.in = (const float *)in; p.out = (float *)out; p.B = B; p.D = D; p.H = H; p.W = W;
+    p.in = in; p.out = out; p.B = B; p.D = D; p.H = H; p.W = W;
     p.tiles_h = (H + TH - 1) / TH; p.tiles_w = (W + TW - 1) / TW; p.tiles_d = (D + TD - 1) / TD;
     const long long n = (long long)B * p.tiles_d * p.tiles_h * p.tiles_w;
     if (n > 0x7fffffffLL) { ss2d_set_error("%s: grid too large", name); return -6; }
     hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)n), block(256);
+    const bool h = dtype == SS2D_DTYPE_BF16;
     if (merge) {
-        if (cl) hipLaunchKernelGGL(cross_merge_kernel<true>, dim3((unsigned)n), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(cross_merge_kernel<false>, dim3((unsigned)n), dim3(256), 0, s, p);
+        if (cl) { if (h) hipLaunchKernelGGL((cross_merge_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_kernel<true, float>), grid, block, 0, s, p); }
+        else    { if (h) hipLaunchKernelGGL((cross_merge_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_kernel<false, float>), grid, block, 0, s, p); }
     } else {
-        if (cl) hipLaunchKernelGGL(cross_scan_kernel<true>, dim3((unsigned)n), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL(cross_scan_kernel<false>, dim3((unsigned)n), dim3(256), 0, s, p);
+        if (cl) { if (h) hipLaunchKernelGGL((cross_scan_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_scan_kernel<true, float>), grid, block, 0, s, p); }
+        else    { if (h) hipLaunchKernelGGL((cross_scan_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_scan_kernel<false, float>), grid, block, 0, s, p); }
     }
     const int rc = (int)hipGetLastError();
     if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));

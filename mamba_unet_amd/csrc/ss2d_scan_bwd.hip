@@ -25,8 +25,10 @@ constexpr int NP = 8;
 constexpr int ACC_WAVE_FLOATS = NP * 2 * 4 * 64;  // per wave: [np][mat][item pair][lane], rows already summed
 
 struct ScanBwdParams {
-    const float *u, *delta, *A, *B, *C, *D, *z, *bias, *dout, *ckpt;
-    float *du, *ddelta, *dA, *dB, *dC, *dD, *dz, *dbias;
+    const void *u, *delta, *B, *C, *z, *dout;   // IO type (fp32 or bf16)
+    const float *A, *D, *bias, *ckpt;
+    void *du, *ddelta, *dz;                      // IO type
+    float *dA, *dB, *dC, *dD, *dbias;            // fp32 accumulators (atomics)
     int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg, rounds, cb;
 };
 
@@ -85,8 +87,8 @@ __device__ __forceinline__ void rows_reduce4x2(float &x0, float x1, float x2, fl
                  : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
 }
 
-template <int NW, bool HAS_Z, bool VEC4>
-__global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdParams p) {
+template <int NW, bool HAS_Z, bool VEC4, typename IO>
+__global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     f4 *tile = reinterpret_cast<f4 *>(smem);                                   // [2][NP*4*16] f4 = 16 KB
     float *acc = reinterpret_cast<float *>(smem + 2 * NP * 4 * 16 * sizeof(f4));  // [NW][ACC_WAVE_FLOATS], 16 KB per wave
@@ -100,8 +102,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
     blk /= p.wgs_per_group;
     const int g = blk % p.G, b = blk / p.G;
     const int L = p.L, N = p.N;
-    const float *__restrict__ Bg = p.B + (size_t)(b * p.G + g) * N * (size_t)L;
-    const float *__restrict__ Cg = p.C + (size_t)(b * p.G + g) * N * (size_t)L;
+    const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * N * (size_t)L;
+    const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * N * (size_t)L;
     float *__restrict__ dBg = p.dB + (size_t)(b * p.G + g) * N * (size_t)L;
     float *__restrict__ dCg = p.dC + (size_t)(b * p.G + g) * N * (size_t)L;
 
@@ -118,19 +120,19 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
             const int n0 = 2 * np, n1 = 2 * np + 1;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const float *__restrict__ M = m ? Cg : Bg;
+                const IO *__restrict__ M = m ? Cg : Bg;
                 f4 lo = f4{0, 0, 0, 0}, hi = f4{0, 0, 0, 0};
                 if (VEC4) {
                     if (pos < L) {
-                        if (n0 < N) lo = *reinterpret_cast<const f4 *>(M + (size_t)n0 * L + pos);
-                        if (n1 < N) hi = *reinterpret_cast<const f4 *>(M + (size_t)n1 * L + pos);
+                        if (n0 < N) lo = ld4(M + (size_t)n0 * L + pos);
+                        if (n1 < N) hi = ld4(M + (size_t)n1 * L + pos);
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (pos + e < L) {
-                            if (n0 < N) lo[e] = M[(size_t)n0 * L + pos + e];
-                            if (n1 < N) hi[e] = M[(size_t)n1 * L + pos + e];
+                            if (n0 < N) lo[e] = ld1(M + (size_t)n0 * L + pos + e);
+                            if (n1 < N) hi[e] = ld1(M + (size_t)n1 * L + pos + e);
                         }
                     }
                 }
@@ -149,9 +151,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
             const size_t rowoff = ((size_t)b * p.dim + c) * (size_t)L;
             const int p0 = base + seg * T;
             float uv[T], dt[T], sg[T], dyv[T], du_[T];
-            load8<VEC4>(p.u + rowoff, p0, L, row_ok, uv);
-            load8<VEC4>(p.delta + rowoff, p0, L, row_ok, dt);
-            load8<VEC4>(p.dout + rowoff, p0, L, row_ok, dyv);
+            load8<VEC4>(static_cast<const IO *>(p.u) + rowoff, p0, L, row_ok, uv);
+            load8<VEC4>(static_cast<const IO *>(p.delta) + rowoff, p0, L, row_ok, dt);
+            load8<VEC4>(static_cast<const IO *>(p.dout) + rowoff, p0, L, row_ok, dyv);
             const float bias = p.bias ? p.bias[c] : 0.0f;
             const float Dc = p.D ? p.D[c] : 0.0f;
             float S = 0.0f;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
             float zs[T], zv[T];  // silu(z) and z when gated
             if (HAS_Z) {
                 // gate: out = y * silu(z) with y = sum_n C h + D u, so y has to be rebuilt first
-                load8<VEC4>(p.z + rowoff, p0, L, row_ok, zv);
+                load8<VEC4>(static_cast<const IO *>(p.z) + rowoff, p0, L, row_ok, zv);
                 f2 y2[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) y2[t] = f2{Dc * uv[t], 0.0f};
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
                     dzv[t] = dyv[t] * y * (s_ * (1.0f + zv[t] * (1.0f - s_)));
                     dyv[t] *= zs[t];
                 }
-                store8<VEC4>(p.dz + rowoff, p0, L, row_ok, dzv);
+                store8<VEC4>(static_cast<IO *>(p.dz) + rowoff, p0, L, row_ok, dzv);
             }
 
             f2 ddt2[T], ddu2[T];
@@ -324,8 +326,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
                 dD_part += dyv[t] * uv[t];
                 db_part += ddo[t];
             }
-            store8<VEC4>(p.du + rowoff, p0, L, row_ok, duo);
-            store8<VEC4>(p.ddelta + rowoff, p0, L, row_ok, ddo);
+            store8<VEC4>(static_cast<IO *>(p.du) + rowoff, p0, L, row_ok, duo);
+            store8<VEC4>(static_cast<IO *>(p.ddelta) + rowoff, p0, L, row_ok, ddo);
             const float sD = row_sum_to_lane15(dD_part), sb = row_sum_to_lane15(db_part);
             if (seg == 15) {
                 dXs[(quad * 4 + row) * 2] += sD;
@@ -368,18 +370,25 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_f32_kernel(const ScanBwdPara
     }
 }
 
-template <int NW, bool HAS_Z, bool VEC4>
+template <int NW, bool HAS_Z, bool VEC4, typename IO>
 int launch_one(const ScanBwdParams &p, size_t lds, hipStream_t s) {
-    auto kern = scan_bwd_f32_kernel<NW, HAS_Z, VEC4>;
+    auto kern = scan_bwd_kernel<NW, HAS_Z, VEC4, IO>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(NW * 64), lds, s, p);
     return (int)hipGetLastError();
 }
-template <int NW>
+template <int NW, typename IO>
 int launch_bwd(const ScanBwdParams &p, bool has_z, bool vec4, size_t lds, hipStream_t s) {
-    if (has_z) return vec4 ? launch_one<NW, true, true>(p, lds, s) : launch_one<NW, true, false>(p, lds, s);
-    return vec4 ? launch_one<NW, false, true>(p, lds, s) : launch_one<NW, false, false>(p, lds, s);
+    if (has_z) return vec4 ? launch_one<NW, true, true, IO>(p, lds, s) : launch_one<NW, true, false, IO>(p, lds, s);
+    return vec4 ? launch_one<NW, false, true, IO>(p, lds, s) : launch_one<NW, false, false, IO>(p, lds, s);
+}
+template <typename IO>
+int launch_bwd_nw(int nw, const ScanBwdParams &p, bool has_z, bool vec4, size_t lds, hipStream_t s) {
+    return nw == 8 ? launch_bwd<8, IO>(p, has_z, vec4, lds, s)
+         : nw == 4 ? launch_bwd<4, IO>(p, has_z, vec4, lds, s)
+         : nw == 2 ? launch_bwd<2, IO>(p, has_z, vec4, lds, s)
+                   : launch_bwd<1, IO>(p, has_z, vec4, lds, s);
 }
 
 }  // namespace
@@ -389,7 +398,7 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
                                        const void *dout, const float *ckpt, void *du, void *ddelta, float *dA,
                                        float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
                                        int dim, int L, int dstate, int ngroups, int delta_softplus, void *stream) {
-    if (dtype != SS2D_DTYPE_F32) { ss2d_set_error("selective_scan_bwd: dtype %d not supported (fp32 only)", dtype); return -1; }
+    if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_bwd: unknown dtype %d", dtype); return -1; }
     if (!u || !delta || !A || !B || !C || !dout || !ckpt || !du || !ddelta || !dA || !dB || !dC) {
         ss2d_set_error("selective_scan_bwd: null required pointer"); return -2; }
     if ((z != nullptr) != (dz != nullptr)) { ss2d_set_error("selective_scan_bwd: z and dz must be given together"); return -2; }
@@ -397,10 +406,10 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
     if (dstate > SS2D_MAX_DSTATE) { ss2d_set_error("selective_scan_bwd: dstate %d > %d", dstate, SS2D_MAX_DSTATE); return -4; }
     if (dim % ngroups) { ss2d_set_error("selective_scan_bwd: dim %d not divisible by ngroups %d", dim, ngroups); return -5; }
     ScanBwdParams p;
-    p.u = (const float *)u; p.delta = (const float *)delta; p.A = A; p.B = (const float *)B; p.C = (const float *)C;
-    p.D = D; p.z = (const float *)z; p.bias = delta_bias; p.dout = (const float *)dout; p.ckpt = ckpt;
-    p.du = (float *)du; p.ddelta = (float *)ddelta; p.dA = dA; p.dB = dB; p.dC = dC; p.dD = D ? dD : nullptr;
-    p.dz = (float *)dz; p.dbias = delta_bias ? ddelta_bias : nullptr;
+    p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
+    p.D = D; p.z = z; p.bias = delta_bias; p.dout = dout; p.ckpt = ckpt;
+    p.du = du; p.ddelta = ddelta; p.dA = dA; p.dB = dB; p.dC = dC; p.dD = D ? dD : nullptr;
+    p.dz = dz; p.dbias = delta_bias ? ddelta_bias : nullptr;
     p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
     p.nchunks = ss2d_scan_num_chunks(L); p.softplus = delta_softplus;
     // channels per workgroup: NW waves x 4 rows x `rounds`
@@ -424,13 +433,12 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
     p.nwg = (int)nwg;
     const size_t lds = 2 * NP * 4 * 16 * sizeof(f4) + (size_t)nw * ACC_WAVE_FLOATS * sizeof(float) +
                        (size_t)nw * rounds * NP * 4 * sizeof(f2) + (size_t)nw * rounds * (64 + 8) * sizeof(float);
+    const uintptr_t amask = dtype == SS2D_DTYPE_BF16 ? 7 : 15;  // 4 elements
     const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dout |
-                                         (uintptr_t)du | (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & 15) == 0);
+                                         (uintptr_t)du | (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
-    int rc = nw == 8 ? launch_bwd<8>(p, z != nullptr, vec4, lds, s)
-           : nw == 4 ? launch_bwd<4>(p, z != nullptr, vec4, lds, s)
-           : nw == 2 ? launch_bwd<2>(p, z != nullptr, vec4, lds, s)
-                     : launch_bwd<1>(p, z != nullptr, vec4, lds, s);
+    int rc = dtype == SS2D_DTYPE_BF16 ? launch_bwd_nw<bf16>(nw, p, z != nullptr, vec4, lds, s)
+                                      : launch_bwd_nw<float>(nw, p, z != nullptr, vec4, lds, s);
     if (rc) ss2d_set_error("selective_scan_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

@@ -25,8 +25,10 @@ constexpr int NP = 8;         // state pairs (dstate <= 16; odd/short dstate pad
 static_assert(CHUNK == SS2D_SCAN_CHUNK, "checkpoint spacing is part of the ABI");
 
 struct ScanFwdParams {
-    const float *u, *delta, *A, *B, *C, *D, *z, *bias;
-    float *out, *last, *ckpt;
+    const void *u, *delta, *B, *C, *z;   // IO type (fp32 or bf16)
+    const float *A, *D, *bias;
+    void *out;                            // IO type
+    float *last, *ckpt;
     int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg;
 };
 
@@ -47,8 +49,8 @@ __device__ __forceinline__ void row_scan_pair(float &hx, float &hy, float &ax, f
 }
 
 // FULL: dstate == 16 known at compile time (the only value Mamba-UNet uses): no per-pair bounds checks
-template <int NW, bool HAS_Z, bool VEC4, bool FULL>
-__global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdParams p) {
+template <int NW, bool HAS_Z, bool VEC4, bool FULL, typename IO>
+__global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p) {
     // [buffer][B|C][(pair*4 + quarter)*16 + seg] ; one f4 = (n,t),(n+1,t),(n,t+1),(n+1,t+1)
     __shared__ f4 tile[2][2][NP * 4 * 16];
 
@@ -63,12 +65,12 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
     const int L = p.L, N = FULL ? 16 : p.N;
 
     const size_t rowoff = ((size_t)b * p.dim + c) * (size_t)L;
-    const float *__restrict__ urow = p.u + rowoff;
-    const float *__restrict__ drow = p.delta + rowoff;
-    const float *__restrict__ zrow = HAS_Z ? p.z + rowoff : nullptr;
-    float *__restrict__ orow = p.out + rowoff;
-    const float *__restrict__ Bg = p.B + (size_t)(b * p.G + g) * N * (size_t)L;
-    const float *__restrict__ Cg = p.C + (size_t)(b * p.G + g) * N * (size_t)L;
+    const IO *__restrict__ urow = static_cast<const IO *>(p.u) + rowoff;
+    const IO *__restrict__ drow = static_cast<const IO *>(p.delta) + rowoff;
+    const IO *__restrict__ zrow = HAS_Z ? static_cast<const IO *>(p.z) + rowoff : nullptr;
+    IO *__restrict__ orow = static_cast<IO *>(p.out) + rowoff;
+    const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * N * (size_t)L;
+    const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * N * (size_t)L;
 
     f2 A2[NP], carry[NP];
 #pragma unroll
@@ -96,19 +98,19 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
             const int n0 = 2 * np, n1 = 2 * np + 1;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
-                const float *__restrict__ M = m ? Cg : Bg;
+                const IO *__restrict__ M = m ? Cg : Bg;
                 f4 lo = f4{0, 0, 0, 0}, hi = f4{0, 0, 0, 0};
                 if (VEC4) {
                     if (pos < L) {
-                        if (n0 < N) lo = *reinterpret_cast<const f4 *>(M + (size_t)n0 * L + pos);
-                        if (n1 < N) hi = *reinterpret_cast<const f4 *>(M + (size_t)n1 * L + pos);
+                        if (n0 < N) lo = ld4(M + (size_t)n0 * L + pos);
+                        if (n1 < N) hi = ld4(M + (size_t)n1 * L + pos);
                     }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         if (pos + e < L) {
-                            if (n0 < N) lo[e] = M[(size_t)n0 * L + pos + e];
-                            if (n1 < N) hi[e] = M[(size_t)n1 * L + pos + e];
+                            if (n0 < N) lo[e] = ld1(M + (size_t)n0 * L + pos + e);
+                            if (n1 < N) hi[e] = ld1(M + (size_t)n1 * L + pos + e);
                         }
                     }
                 }
@@ -217,20 +219,25 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_f32_kernel(const ScanFwdPara
     }
 }
 
-template <int NW>
+template <int NW, typename IO>
 int launch_fwd(const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
     dim3 grid(p.nwg), block(NW * 64);
     const bool full = p.N == 16;
     if (has_z) {
-        if (vec4) hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, true, true, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, true, false, false>), grid, block, 0, s, p);
+        if (vec4) hipLaunchKernelGGL((scan_fwd_kernel<NW, true, true, false, IO>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scan_fwd_kernel<NW, true, false, false, IO>), grid, block, 0, s, p);
     } else if (vec4 && full) {
-        hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, true, true>), grid, block, 0, s, p);  // the SS2D call pattern
+        hipLaunchKernelGGL((scan_fwd_kernel<NW, false, true, true, IO>), grid, block, 0, s, p);  // the SS2D call pattern
     } else {
-        if (vec4) hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, true, false>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scan_fwd_f32_kernel<NW, false, false, false>), grid, block, 0, s, p);
+        if (vec4) hipLaunchKernelGGL((scan_fwd_kernel<NW, false, true, false, IO>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scan_fwd_kernel<NW, false, false, false, IO>), grid, block, 0, s, p);
     }
     return (int)hipGetLastError();
+}
+template <typename IO>
+int launch_fwd_nw(int nw, const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
+    return nw == 4 ? launch_fwd<4, IO>(p, has_z, vec4, s) : nw == 2 ? launch_fwd<2, IO>(p, has_z, vec4, s)
+                                                                     : launch_fwd<1, IO>(p, has_z, vec4, s);
 }
 
 }  // namespace
@@ -245,14 +252,14 @@ extern "C" int ss2d_selective_scan_fwd(int dtype, const void *u, const void *del
                                        const void *C, const float *D, const void *z, const float *delta_bias,
                                        void *out, float *last_state, float *ckpt, int batch, int dim, int L,
                                        int dstate, int ngroups, int delta_softplus, void *stream) {
-    if (dtype != SS2D_DTYPE_F32) { ss2d_set_error("selective_scan_fwd: dtype %d not supported (fp32 only)", dtype); return -1; }
+    if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_fwd: unknown dtype %d", dtype); return -1; }
     if (!u || !delta || !A || !B || !C || !out) { ss2d_set_error("selective_scan_fwd: null required pointer"); return -2; }
     if (batch <= 0 || dim <= 0 || L <= 0 || dstate <= 0 || ngroups <= 0) { ss2d_set_error("selective_scan_fwd: non-positive size"); return -3; }
     if (dstate > SS2D_MAX_DSTATE) { ss2d_set_error("selective_scan_fwd: dstate %d > %d", dstate, SS2D_MAX_DSTATE); return -4; }
     if (dim % ngroups) { ss2d_set_error("selective_scan_fwd: dim %d not divisible by ngroups %d", dim, ngroups); return -5; }
     ScanFwdParams p;
-    p.u = (const float *)u; p.delta = (const float *)delta; p.A = A; p.B = (const float *)B; p.C = (const float *)C;
-    p.D = D; p.z = (const float *)z; p.bias = delta_bias; p.out = (float *)out; p.last = last_state; p.ckpt = ckpt;
+    p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
+    p.D = D; p.z = z; p.bias = delta_bias; p.out = out; p.last = last_state; p.ckpt = ckpt;
     p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
     p.nchunks = ss2d_scan_num_chunks(L); p.softplus = delta_softplus;
     int nw = p.dpg >= 16 ? 4 : (p.dpg >= 8 ? 2 : 1);
@@ -261,11 +268,12 @@ extern "C" int ss2d_selective_scan_fwd(int dtype, const void *u, const void *del
     const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
     if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_fwd: grid too large"); return -6; }
     p.nwg = (int)nwg;
+    const uintptr_t amask = dtype == SS2D_DTYPE_BF16 ? 7 : 15;  // 4 elements
     const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)out |
-                                         (uintptr_t)z) & 15) == 0);
+                                         (uintptr_t)z) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
-    int rc = nw == 4 ? launch_fwd<4>(p, z != nullptr, vec4, s) : nw == 2 ? launch_fwd<2>(p, z != nullptr, vec4, s)
-                                                                            : launch_fwd<1>(p, z != nullptr, vec4, s);
+    int rc = dtype == SS2D_DTYPE_BF16 ? launch_fwd_nw<bf16>(nw, p, z != nullptr, vec4, s)
+                                      : launch_fwd_nw<float>(nw, p, z != nullptr, vec4, s);
     if (rc) ss2d_set_error("selective_scan_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

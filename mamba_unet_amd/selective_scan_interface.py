@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-_F32 = 0
+_F32, _BF16 = 0, 1          # include/ss2d.h: SS2D_DTYPE_F32 / SS2D_DTYPE_BF16
 
 
 def _stream():
@@ -39,6 +39,9 @@ class SelectiveScanFn(torch.autograd.Function):
         if u.dim() != 3 or delta.shape != u.shape:
             raise ValueError(f"u/delta must be (batch, dim, L) and equal: {tuple(u.shape)} vs {tuple(delta.shape)}")
         in_dtype = u.dtype
+        # storage type of u, delta, B, C, z, out and their gradients inside the kernels: bf16 stays bf16
+        # (half the HBM bytes; arithmetic, A, D, delta_bias, the state checkpoints and dA/dB/dC/dD are fp32)
+        io = torch.bfloat16 if in_dtype == torch.bfloat16 else torch.float32
         batch, dim, L = u.shape
         dstate = A.shape[1]
         if A.shape[0] != dim:
@@ -59,9 +62,10 @@ class SelectiveScanFn(torch.autograd.Function):
         if z is not None and z.shape != u.shape:
             raise ValueError("z must have u's shape")
 
-        u_, delta_ = _prep(u, "u"), _prep(delta, "delta")
-        A_, B_, C_ = _prep(A, "A"), _prep(B4, "B"), _prep(C4, "C")
-        D_, z_, bias_ = _prep(D, "D"), _prep(z, "z"), _prep(delta_bias, "delta_bias")
+        u_, delta_ = _prep(u, "u", io), _prep(delta, "delta", io)
+        A_, B_, C_ = _prep(A, "A"), _prep(B4, "B", io), _prep(C4, "C", io)
+        D_, z_, bias_ = _prep(D, "D"), _prep(z, "z", io), _prep(delta_bias, "delta_bias")
+        ctx.code = code = _BF16 if io == torch.bfloat16 else _F32
         needs_grad = any(t is not None and t.requires_grad for t in (u, delta, A, B, C, D, z, delta_bias))
         lib = _lib.load()
         out = torch.empty_like(u_)
@@ -70,7 +74,7 @@ class SelectiveScanFn(torch.autograd.Function):
         if needs_grad:
             ckpt = torch.empty((batch, dim, lib.ss2d_scan_num_chunks(L), dstate), device=u_.device, dtype=torch.float32)
         with torch.cuda.device(u_.device):
-            rc = lib.ss2d_selective_scan_fwd(_F32, _lib.ptr(u_), _lib.ptr(delta_), _lib.ptr(A_), _lib.ptr(B_),
+            rc = lib.ss2d_selective_scan_fwd(code, _lib.ptr(u_), _lib.ptr(delta_), _lib.ptr(A_), _lib.ptr(B_),
                                              _lib.ptr(C_), _lib.ptr(D_), _lib.ptr(z_), _lib.ptr(bias_),
                                              _lib.ptr(out), _lib.ptr(last), _lib.ptr(ckpt), batch, dim, L, dstate, G,
                                              int(bool(delta_softplus)), _stream())
@@ -92,16 +96,16 @@ class SelectiveScanFn(torch.autograd.Function):
         u, delta, A, B, C, D, z, bias, ckpt = ctx.saved_tensors
         batch, dim, L = u.shape
         dstate, G = A.shape[1], B.shape[1]
-        dout = _prep(dout, "dout")
+        dout = _prep(dout, "dout", u.dtype)
         lib = _lib.load()
         du, ddelta = torch.empty_like(u), torch.empty_like(u)
         dA = torch.zeros_like(A)
-        dB, dC = torch.zeros_like(B), torch.zeros_like(C)
+        dB, dC = torch.zeros_like(B, dtype=torch.float32), torch.zeros_like(C, dtype=torch.float32)
         dD = torch.zeros_like(D) if D is not None else None
         dz = torch.empty_like(z) if z is not None else None
         dbias = torch.zeros_like(bias) if bias is not None else None
         with torch.cuda.device(u.device):
-            rc = lib.ss2d_selective_scan_bwd(_F32, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B), _lib.ptr(C),
+            rc = lib.ss2d_selective_scan_bwd(ctx.code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B), _lib.ptr(C),
                                              _lib.ptr(D), _lib.ptr(z), _lib.ptr(bias), _lib.ptr(dout), _lib.ptr(ckpt),
                                              _lib.ptr(du), _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC),
                                              _lib.ptr(dD), _lib.ptr(dz), _lib.ptr(dbias), batch, dim, L, dstate, G,

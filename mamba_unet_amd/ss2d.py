@@ -116,6 +116,8 @@ class SS2D(nn.Module):
         Dv._no_weight_decay = True
         return Dv
 
+    bf16_scan_io = False   # class-wide switch (set SS2D.bf16_scan_io = True, e.g. bench_model.py --dtype bf16)
+
     # ---- mamba_sys.py:396-461
     def forward_corev0(self, x: torch.Tensor):
         """x (B, D, H, W) -> (B, H, W, D), normalised."""
@@ -127,13 +129,17 @@ class SS2D(nn.Module):
         x_dbl = torch.matmul(self.x_proj_weight.unsqueeze(0), xs)                 # (B, K, R+2N, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = torch.matmul(self.dt_projs_weight.unsqueeze(0), dts)               # (B, K, D, L)
+        # The reference casts the four scan inputs to fp32 here (:423-426), also under autocast.  With
+        # `bf16_scan_io` (build's addition, off by default) bf16 activations go to the kernels as they are:
+        # half the HBM bytes for u/delta/B/C/y and their gradients, fp32 arithmetic and state inside.
+        cast = (lambda t: t) if (self.bf16_scan_io and xs.dtype == torch.bfloat16) else (lambda t: t.float())
         out_y = selective_scan_fn(
-            xs.float().reshape(B, K * D, L), dts.float().reshape(B, K * D, L),
+            cast(xs).reshape(B, K * D, L), cast(dts).reshape(B, K * D, L),
             -torch.exp(self.A_logs.float()).view(K * D, N),
-            Bs.float().reshape(B, K, N, L), Cs.float().reshape(B, K, N, L),
+            cast(Bs).reshape(B, K, N, L), cast(Cs).reshape(B, K, N, L),
             self.Ds.float().view(-1), z=None, delta_bias=self.dt_projs_bias.float().view(-1),
             delta_softplus=True, return_last_state=False)
-        assert out_y.dtype == torch.float32
+        assert out_y.dtype == (torch.bfloat16 if (self.bf16_scan_io and xs.dtype == torch.bfloat16) else torch.float32)
         y = cross_merge(out_y.view(B, K, D, L), H, W, channel_last=True)         # (B, H, W, D)
         return self.out_norm(y).to(x.dtype)
 

@@ -8,7 +8,12 @@ import torch
 
 from . import _lib
 
-_F32 = 0
+_F32, _BF16 = 0, 1          # include/ss2d.h: SS2D_DTYPE_F32 / SS2D_DTYPE_BF16
+
+
+def _io(t):
+    """storage type inside the kernels: bf16 tensors stay bf16, everything else goes through fp32"""
+    return (torch.bfloat16, _BF16) if t.dtype == torch.bfloat16 else (torch.float32, _F32)
 
 
 def _stream():
@@ -26,10 +31,11 @@ class _CrossScan(torch.autograd.Function):
         _need_gpu(x, "cross_scan")
         B, D, H, W = x.shape
         in_dtype = x.dtype
-        xf = x.float().contiguous()
-        xs = torch.empty((B, 4, D, H * W), device=x.device, dtype=torch.float32)
+        io, code = _io(x)
+        xf = x.to(io).contiguous()
+        xs = torch.empty((B, 4, D, H * W), device=x.device, dtype=io)
         with torch.cuda.device(x.device):
-            rc = _lib.load().ss2d_cross_scan_fwd(_F32, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, _stream())
+            rc = _lib.load().ss2d_cross_scan_fwd(code, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, _stream())
         _lib.check(rc, "ss2d_cross_scan_fwd")
         ctx.shape, ctx.in_dtype = (B, D, H, W), in_dtype
         return xs.to(in_dtype)
@@ -37,10 +43,11 @@ class _CrossScan(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dxs):
         B, D, H, W = ctx.shape
-        g = dxs.float().contiguous()
-        dx = torch.empty((B, D, H, W), device=g.device, dtype=torch.float32)
+        io, code = _io(dxs)
+        g = dxs.to(io).contiguous()
+        dx = torch.empty((B, D, H, W), device=g.device, dtype=io)
         with torch.cuda.device(g.device):
-            rc = _lib.load().ss2d_cross_scan_bwd(_F32, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, _stream())
+            rc = _lib.load().ss2d_cross_scan_bwd(code, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, _stream())
         _lib.check(rc, "ss2d_cross_scan_bwd")
         return dx.to(ctx.in_dtype)
 
@@ -53,11 +60,12 @@ class _CrossMerge(torch.autograd.Function):
         if K != 4 or L != H * W:
             raise ValueError(f"cross_merge: expected (B, 4, D, {H * W}), got {tuple(ys.shape)}")
         in_dtype = ys.dtype
-        yf = ys.float().contiguous()
+        io, code = _io(ys)
+        yf = ys.to(io).contiguous()
         shape = (B, H, W, D) if channel_last else (B, D, L)
-        y = torch.empty(shape, device=ys.device, dtype=torch.float32)
+        y = torch.empty(shape, device=ys.device, dtype=io)
         with torch.cuda.device(ys.device):
-            rc = _lib.load().ss2d_cross_merge_fwd(_F32, _lib.ptr(yf), _lib.ptr(y), B, D, H, W, int(channel_last), _stream())
+            rc = _lib.load().ss2d_cross_merge_fwd(code, _lib.ptr(yf), _lib.ptr(y), B, D, H, W, int(channel_last), _stream())
         _lib.check(rc, "ss2d_cross_merge_fwd")
         ctx.dims, ctx.in_dtype = (B, D, H, W, int(channel_last)), in_dtype
         return y.to(in_dtype)
@@ -65,10 +73,11 @@ class _CrossMerge(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         B, D, H, W, cl = ctx.dims
-        g = dy.float().contiguous()
-        dys = torch.empty((B, 4, D, H * W), device=g.device, dtype=torch.float32)
+        io, code = _io(dy)
+        g = dy.to(io).contiguous()
+        dys = torch.empty((B, 4, D, H * W), device=g.device, dtype=io)
         with torch.cuda.device(g.device):
-            rc = _lib.load().ss2d_cross_merge_bwd(_F32, _lib.ptr(g), _lib.ptr(dys), B, D, H, W, cl, _stream())
+            rc = _lib.load().ss2d_cross_merge_bwd(code, _lib.ptr(g), _lib.ptr(dys), B, D, H, W, cl, _stream())
         _lib.check(rc, "ss2d_cross_merge_bwd")
         return dys.to(ctx.in_dtype), None, None, None
 
@@ -78,40 +87,41 @@ class _DwConvSiLU(torch.autograd.Function):
     def forward(ctx, x, weight, bias, channel_last_in):
         _need_gpu(x, "dwconv3x3_silu")
         in_dtype = x.dtype
+        io, code = _io(x)
         if channel_last_in:
             B, H, W, D = x.shape
-            xf = x.float()
+            xf = x.to(io)
             # accept a channel slice of a wider tensor (the x half of xz): unit channel stride, dense (b,h,w)
             if not (xf.stride(3) == 1 and xf.stride(1) == W * xf.stride(2) and xf.stride(0) == H * W * xf.stride(2)):
                 xf = xf.contiguous()
             ldx = xf.stride(2)
         else:
             B, D, H, W = x.shape
-            xf = x.float().contiguous()
+            xf = x.to(io).contiguous()
             ldx = D
         if tuple(weight.shape) != (D, 1, 3, 3):
             raise ValueError(f"dwconv3x3_silu: weight must be ({D}, 1, 3, 3), got {tuple(weight.shape)}")
         wf = weight.float().contiguous()
         bf = None if bias is None else bias.float().contiguous()
-        y = torch.empty((B, D, H, W), device=x.device, dtype=torch.float32)
+        y = torch.empty((B, D, H, W), device=x.device, dtype=io)
         with torch.cuda.device(x.device):
-            rc = _lib.load().ss2d_dwconv3x3_silu_fwd(_F32, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(y),
+            rc = _lib.load().ss2d_dwconv3x3_silu_fwd(code, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(y),
                                                      B, D, H, W, int(channel_last_in), ldx, _stream())
         _lib.check(rc, "ss2d_dwconv3x3_silu_fwd")
         ctx.save_for_backward(xf, wf, bf)
-        ctx.meta = (B, D, H, W, int(channel_last_in), ldx, in_dtype, weight.dtype, None if bias is None else bias.dtype)
+        ctx.meta = (B, D, H, W, int(channel_last_in), ldx, in_dtype, weight.dtype, None if bias is None else bias.dtype, code)
         return y.to(in_dtype)
 
     @staticmethod
     def backward(ctx, dy):
         xf, wf, bf = ctx.saved_tensors
-        B, D, H, W, cl, ldx, in_dtype, w_dtype, b_dtype = ctx.meta
-        g = dy.float().contiguous()
-        dx = torch.empty((B, H, W, D) if cl else (B, D, H, W), device=g.device, dtype=torch.float32)
+        B, D, H, W, cl, ldx, in_dtype, w_dtype, b_dtype, code = ctx.meta
+        g = dy.to(xf.dtype).contiguous()
+        dx = torch.empty((B, H, W, D) if cl else (B, D, H, W), device=g.device, dtype=xf.dtype)
         dw = torch.zeros_like(wf)
         db = torch.zeros_like(bf) if bf is not None else None
         with torch.cuda.device(g.device):
-            rc = _lib.load().ss2d_dwconv3x3_silu_bwd(_F32, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(g),
+            rc = _lib.load().ss2d_dwconv3x3_silu_bwd(code, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(g),
                                                      _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), B, D, H, W, cl, ldx, D,
                                                      _stream())
         _lib.check(rc, "ss2d_dwconv3x3_silu_bwd")
