@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--batch", type=int, default=24, help="slices per GPU")
     ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16-fp32scan"], default="fp32",
                     help="bf16: autocast + bf16 kernel I/O; bf16-fp32scan: autocast with the reference's fp32 casts around the scan")
+    ap.add_argument("--graph", action="store_true", help="train mode, 1 GPU: capture the whole step in a HIP graph")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -54,7 +55,7 @@ def main():
 
     from mamba_unet_amd import MambaUnet
     from mamba_unet_amd.dist import wrap_ddp
-    from mamba_unet_amd.train import make_sgd, semi_step, supervised_step
+    from mamba_unet_amd.train import GraphedSupervisedStep, make_sgd, semi_step, supervised_step
 
     bf16 = args.dtype != "fp32"
     from mamba_unet_amd import SS2D
@@ -75,10 +76,17 @@ def main():
                 return net(images)
     elif args.mode == "train":
         net = wrap_ddp(nets[0].train(), local)
-        opt = make_sgd(net.parameters())
+        if args.graph and world == 1:
+            opt = make_sgd(net.parameters(), tensor_lr_device=dev)
+            gstep = GraphedSupervisedStep(net, opt, images, labels, args.classes, max_it, autocast_bf16=bf16)
 
-        def step(it):
-            return supervised_step(net, opt, images, labels, args.classes, it, max_it, autocast_bf16=bf16)
+            def step(it):
+                return gstep(gstep.images, gstep.labels, it)
+        else:
+            opt = make_sgd(net.parameters())
+
+            def step(it):
+                return supervised_step(net, opt, images, labels, args.classes, it, max_it, autocast_bf16=bf16)
     else:
         n1, n2 = (wrap_ddp(n.train(), local) for n in nets)
         o1, o2 = make_sgd(n1.parameters()), make_sgd(n2.parameters())
@@ -116,6 +124,7 @@ def main():
             "config": {"workload": f"MambaUNet (VSSM tiny, depths 2-2-2-2, {n_params} params) {args.mode}, batch "
                                    f"{args.batch} per GPU, {args.size}x{args.size}, {args.classes} classes",
                        "parallelism": f"DDP x{world} (batch-sharded slices, RCCL gradient all-reduce)"},
+            "hip_graph": bool(args.graph and world == 1 and args.mode == "train"),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "finite": finite}))
     if dist is not None:
         dist.destroy_process_group()

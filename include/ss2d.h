@@ -85,6 +85,14 @@ int ss2d_dwconv3x3_silu_bwd(int dtype, const void *x, const float *w, const floa
                             void *dx, float *dw, float *dbias, int B, int D, int H, int W, int channel_last_in,
                             int ldx, int lddx, void *stream);
 
+/* Weight gradient of the bias-free in_proj / out_proj Linears (mamba_sys.py:298, :337; used :555, :562; the
+ * reference gets it from autograd of nn.Linear): C[m][n] += sum_r A[r][m] * B[r][n] with A = dL/d(output)
+ * (rows x M, row stride lda), B = the Linear's input (rows x N, row stride ldb), rows = batch*H*W tokens,
+ * C = dL/dweight (M x N fp32, row stride ldc), ACCUMULATED INTO with float atomics: caller zero-fills.
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32); bf16 operands are widened exactly, products and sums stay fp32. */
+int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float *C, long long rows, int M, int N, int lda,
+                      int ldb, int ldc, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

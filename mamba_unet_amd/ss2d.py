@@ -20,7 +20,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import selective_scan_fn
-from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu
+from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_nobias
 
 
 class DropPath(nn.Module):
@@ -146,12 +146,12 @@ class SS2D(nn.Module):
     # ---- mamba_sys.py:552-565
     def forward(self, x: torch.Tensor, **kwargs):
         D = self.d_inner
-        xz = self.in_proj(x)                                                      # (B, H, W, 2D)
+        xz = linear_nobias(x, self.in_proj.weight) if self.in_proj.bias is None else self.in_proj(x)   # (B, H, W, 2D)
         z = xz[..., D:]
         xc = dwconv3x3_silu(xz[..., :D], self.conv2d.weight, self.conv2d.bias, channel_last_in=True)
         y = self.forward_core(xc)
         y = y * F.silu(z)
-        out = self.out_proj(y)
+        out = linear_nobias(y, self.out_proj.weight) if self.out_proj.bias is None else self.out_proj(y)
         if self.dropout is not None:
             out = self.dropout(out)
         return out

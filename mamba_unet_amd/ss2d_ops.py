@@ -4,6 +4,8 @@ Reference lines they replace: cross-scan mamba_sys.py:403-404, cross-merge :445-
 `act(conv2d(x.permute(0,3,1,2).contiguous()))` :558-559.  GPU tensors only (no CPU path)."""
 from __future__ import annotations
 
+import os as _os
+
 import torch
 
 from . import _lib
@@ -142,3 +144,59 @@ def dwconv3x3_silu(x: torch.Tensor, weight: torch.Tensor, bias, channel_last_in:
     """SiLU(depthwise conv3x3(x) + bias) -> (B, D, H, W).  x is (B, H, W, D) (channel_last_in; may be a
     channel slice of a wider tensor) or (B, D, H, W).  mamba_sys.py:299-308, :558-559."""
     return _DwConvSiLU.apply(x, weight, bias, channel_last_in)
+
+
+def linear_wgrad(grad_out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
+    """dW (M, N) fp32 of a bias-free Linear: sum over all leading axes of grad_out[..., M]^T inp[..., N], on the
+    MFMA kernel of csrc/ss2d_wgrad.hip (mamba_sys.py:298/:337 in_proj / out_proj).  bf16 or fp32 operands."""
+    _need_gpu(grad_out, "linear_wgrad")
+    M, N = grad_out.shape[-1], inp.shape[-1]
+    io, code = _io(grad_out)
+    g2 = grad_out.reshape(-1, M).to(io)
+    x2 = inp.reshape(-1, N).to(io)
+    if g2.stride(1) != 1:
+        g2 = g2.contiguous()
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    if g2.shape[0] != x2.shape[0]:
+        raise ValueError(f"linear_wgrad: {tuple(grad_out.shape)} and {tuple(inp.shape)} disagree on the token axes")
+    dw = torch.zeros((M, N), device=grad_out.device, dtype=torch.float32)
+    with torch.cuda.device(grad_out.device):
+        rc = _lib.load().ss2d_linear_wgrad(code, _lib.ptr(g2), _lib.ptr(x2), _lib.ptr(dw), g2.shape[0], M, N,
+                                           g2.stride(0), x2.stride(0), N, _stream())
+    _lib.check(rc, "ss2d_linear_wgrad")
+    return dw
+
+
+class _LinearNoBias(torch.autograd.Function):
+    """y = x W^T for the projections whose token axis dwarfs both feature axes: forward and dX stay on
+    hipBLASLt (F.linear / matmul, good shapes), dW goes to the split-token MFMA kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            x, w = x.to(dt), weight.to(dt)
+        else:
+            w = weight
+        ctx.save_for_backward(x, w)
+        ctx.w_dtype = weight.dtype
+        with torch.autocast("cuda", enabled=False):
+            return torch.nn.functional.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g = g.to(x.dtype)
+        dx = torch.matmul(g, w) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(g, x).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
+        return dx, dw
+
+
+def linear_nobias(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """F.linear(x, weight) with the weight gradient on the MFMA split-token kernel when the token axis is long
+    (>= 32x the smaller feature axis: stages 0 and 1 of MambaUNet); plain F.linear otherwise."""
+    rows = x.numel() // x.shape[-1]
+    if x.is_cuda and rows >= 32 * min(weight.shape) and not _os.environ.get("SS2D_NO_WGRAD"):   # env: A/B switch
+        return _LinearNoBias.apply(x, weight)
+    return torch.nn.functional.linear(x, weight)

@@ -44,8 +44,54 @@ def poly_lr(base_lr: float, it: int, max_it: int) -> float:
     return base_lr * (1.0 - it / max_it) ** 0.9
 
 
-def make_sgd(params, lr=0.01):
+class CapturableSGD:
+    """torch.optim.SGD(momentum, weight_decay; dampening 0, no nesterov) with the learning rate in a 0-dim device
+    tensor and no host read of it, so the update can sit inside a captured HIP graph (torch's foreach SGD calls
+    .item() on a tensor lr).  Same arithmetic: d = g + wd*p; buf = d (first step) or mu*buf + d; p -= lr*buf."""
+
+    def __init__(self, params, lr, momentum=0.9, weight_decay=1e-4, device=None):
+        self.params = [p for p in params if p.requires_grad]
+        device = device or self.params[0].device
+        self.param_groups = [{"lr": torch.tensor(float(lr), device=device), "momentum": momentum,
+                              "weight_decay": weight_decay, "params": self.params}]
+        self.bufs = None
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if set_to_none:
+                p.grad = None
+            elif p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self):
+        g = self.param_groups[0]
+        ps = [p for p in self.params if p.grad is not None]
+        d = torch._foreach_add([p.grad for p in ps], ps, alpha=g["weight_decay"])
+        if self.bufs is None:
+            self.bufs = {id(p): t.clone() for p, t in zip(ps, d)}
+            bufs = [self.bufs[id(p)] for p in ps]
+        else:
+            bufs = [self.bufs[id(p)] for p in ps]
+            torch._foreach_mul_(bufs, g["momentum"])
+            torch._foreach_add_(bufs, d)
+        torch._foreach_sub_(ps, torch._foreach_mul(bufs, g["lr"]))
+
+
+def make_sgd(params, lr=0.01, tensor_lr_device=None):
+    """SGD of train_fully_supervised_2D_VIM.py:117-118.  With `tensor_lr_device` the learning rate lives in a
+    0-dim device tensor so that a HIP-graph-captured step (GraphedSupervisedStep) sees the poly-LR updates."""
+    if tensor_lr_device is not None:
+        return CapturableSGD(params, lr, momentum=0.9, weight_decay=1e-4, device=tensor_lr_device)
     return torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4)
+
+
+def set_lr(optimizer, lr: float):
+    for g in optimizer.param_groups:
+        if isinstance(g["lr"], torch.Tensor):
+            g["lr"].fill_(lr)
+        else:
+            g["lr"] = lr
 
 
 def supervised_step(model, optimizer, images, labels, n_classes, it, max_it, base_lr=0.01, autocast_bf16=False):
@@ -60,10 +106,38 @@ def supervised_step(model, optimizer, images, labels, n_classes, it, max_it, bas
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
     optimizer.step()
-    lr = poly_lr(base_lr, it, max_it)
-    for g in optimizer.param_groups:
-        g["lr"] = lr
+    set_lr(optimizer, poly_lr(base_lr, it, max_it))
     return loss.detach()
+
+
+class GraphedSupervisedStep:
+    """The whole supervised iteration (forward, loss, backward, SGD update) captured once in a HIP graph and
+    replayed: the step has ~2000 kernel launches and is launch-bound on the host at batch 24, a replay costs one
+    launch.  Single process / single GPU (DDP's bucketed all-reduce is not captured here).  Inputs are copied into
+    static buffers; the learning rate must be a device tensor (make_sgd(..., tensor_lr_device=dev))."""
+
+    def __init__(self, model, optimizer, images, labels, n_classes, max_it, base_lr=0.01, autocast_bf16=False, warmup=3):
+        self.opt, self.max_it, self.base_lr = optimizer, max_it, base_lr
+        self.images, self.labels = images.clone(), labels.clone()
+        args = (model, optimizer, self.images, self.labels, n_classes)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(warmup):   # allocator, MIOpen / hipBLASLt heuristics and autograd warm up eagerly
+                supervised_step(*args, i, max_it, base_lr, autocast_bf16)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph):
+            self.loss = supervised_step(*args, warmup, max_it, base_lr, autocast_bf16)
+
+    def __call__(self, images, labels, it):
+        if images is not self.images:
+            self.images.copy_(images)
+            self.labels.copy_(labels)
+        self.graph.replay()
+        set_lr(self.opt, poly_lr(self.base_lr, it, self.max_it))
+        return self.loss
 
 
 def semi_step(model1, model2, opt1, opt2, images, labels, labeled_bs, n_classes, it, max_it, consistency_weight,
@@ -85,8 +159,6 @@ def semi_step(model1, model2, opt1, opt2, images, labels, labeled_bs, n_classes,
     loss.backward()
     opt1.step()
     opt2.step()
-    lr = poly_lr(base_lr, it, max_it)
     for opt in (opt1, opt2):
-        for g in opt.param_groups:
-            g["lr"] = lr
+        set_lr(opt, poly_lr(base_lr, it, max_it))
     return loss.detach()

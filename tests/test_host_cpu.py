@@ -90,3 +90,22 @@ def test_mambaunet_wrapper_and_state_dict_roundtrip(tmp_path):
     # encoder stage N also seeds decoder stage 3-N where shapes agree (vision_mamba.py:69-80)
     k_up = "layers_up.1.blocks.0.self_attention.A_logs"
     assert torch.equal(sb[k_up], sa["layers.2.blocks.0.self_attention.A_logs"])
+
+
+def test_capturable_sgd_matches_torch_sgd():
+    """CapturableSGD (tensor lr, graph-safe) == torch.optim.SGD(momentum .9, wd 1e-4) over several steps."""
+    import torch
+    from mamba_unet_amd.train import CapturableSGD, set_lr
+    torch.manual_seed(0)
+    a = [torch.randn(5, 3, requires_grad=True), torch.randn(7, requires_grad=True)]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    o1 = torch.optim.SGD(a, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    o2 = CapturableSGD(b, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for it in range(4):
+        for ps, o in ((a, o1), (b, o2)):
+            o.zero_grad(set_to_none=True)
+            (sum((p ** 2).sum() * (k + 1) for k, p in enumerate(ps)) + ps[0].sin().sum()).backward()
+            o.step()
+            set_lr(o, 0.01 * (1 - it / 10) ** 0.9)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
