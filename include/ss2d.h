@@ -93,6 +93,17 @@ int ss2d_dwconv3x3_silu_bwd(int dtype, const void *x, const float *w, const floa
 int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float *C, long long rows, int M, int N, int lda,
                       int ldb, int ldc, void *stream);
 
+/* Fused out_norm + gate (mamba_sys.py:336/:452 LayerNorm(D) eps, :561 `y * F.silu(z)`):
+ *   out[r][d] = ((y[r][d] - mean_r) * rstd_r * gamma[d] + beta[d]) * silu(z[r][d]),  rows = batch*H*W tokens.
+ *   y, out, dout, dy: (rows, D) dense; z: row stride ldz (the z half of the in_proj output is read in place,
+ *   ldz = 2*D); dz: row stride lddz.  mean/rstd (rows, fp32) are written by _fwd when non-NULL and read by _bwd.
+ *   dgamma, dbeta (D, fp32) are ACCUMULATED INTO with float atomics: caller zero-fills.  D % 4 == 0, D <= 1536. */
+int ss2d_outnorm_gate_fwd(int dtype, const void *y, const void *z, const float *gamma, const float *beta, void *out,
+                          float *mean, float *rstd, long long rows, int D, int ldz, float eps, void *stream);
+int ss2d_outnorm_gate_bwd(int dtype, const void *dout, const void *y, const void *z, const float *gamma,
+                          const float *beta, const float *mean, const float *rstd, void *dy, void *dz, float *dgamma,
+                          float *dbeta, long long rows, int D, int ldz, int lddz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

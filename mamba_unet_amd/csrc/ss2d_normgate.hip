@@ -1,0 +1,227 @@
+// Fused out_norm + gate of SS2D for gfx950:  out = (LayerNorm_D(y) * gamma + beta) * SiLU(z)
+// (/root/reference/code/networks/mamba_sys.py:336 `out_norm`, :452 applied, :561 `y * F.silu(z)`), forward and
+// backward.  The reference runs LayerNorm, SiLU and the product as three elementwise passes (plus their three
+// backward passes); here one pass reads y and z and writes out, one pass computes dy, dz, dgamma, dbeta.
+//
+// One wave per token row (D = 192 ... 1536 channels: 4-element chunks strided over the 64 lanes, kept in
+// registers), wave-level butterfly sums for the statistics, fp32 arithmetic in both storage types.
+// z is read in place from the z half of the in_proj output (row stride ldz), dz is written with row stride lddz.
+// dgamma / dbeta: per-lane column sums over the rows a wave walks, then one float atomic per column and wave.
+#include "ss2d_common.h"
+#include "../../include/ss2d.h"
+
+namespace {
+
+constexpr int MAXK = 6;  // 4 * 64 * MAXK = 1536 channels max
+
+struct NormGateParams {
+    const void *y, *z, *dout;
+    const float *gamma, *beta;
+    void *out, *dy, *dz;
+    float *mean, *rstd, *dgamma, *dbeta;
+    long long rows;
+    int D, ldz, lddz;
+    float eps;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int K, typename IO>
+__global__ __launch_bounds__(256) void normgate_fwd_kernel(const NormGateParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const int D = p.D, nchunk = D >> 2;
+    const IO *__restrict__ Y = static_cast<const IO *>(p.y);
+    const IO *__restrict__ Z = static_cast<const IO *>(p.z);
+    IO *__restrict__ O = static_cast<IO *>(p.out);
+    f4 g[K], b[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = lane + 64 * k;
+        g[k] = c < nchunk ? ld4(p.gamma + 4 * c) : f4{0, 0, 0, 0};
+        b[k] = c < nchunk ? ld4(p.beta + 4 * c) : f4{0, 0, 0, 0};
+    }
+    const float invD = 1.0f / (float)D;
+    for (long long r = wave0; r < p.rows; r += nwaves) {
+        f4 yv[K], zv[K];
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + 64 * k;
+            yv[k] = c < nchunk ? ld4(Y + r * D + 4 * c) : f4{0, 0, 0, 0};
+            zv[k] = c < nchunk ? ld4(Z + r * p.ldz + 4 * c) : f4{0, 0, 0, 0};
+            s += (yv[k].x + yv[k].y) + (yv[k].z + yv[k].w);
+        }
+        const float mu = wave_sum(s) * invD;
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nchunk) {
+                const f4 d = yv[k] - mu;
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+        }
+        const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * invD + p.eps);
+        if (lane == 0 && p.mean) { p.mean[r] = mu; p.rstd[r] = rstd; }
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nchunk) {
+                f4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = (yv[k][e] - mu) * rstd * g[k][e] + b[k][e];
+                    const float zz = zv[k][e];
+                    o[e] = v * (zz * sigmoidf_fast(zz));
+                }
+                st4(O + r * D + 4 * c, o);
+            }
+        }
+    }
+}
+
+template <int K, typename IO>
+__global__ __launch_bounds__(256) void normgate_bwd_kernel(const NormGateParams p) {
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const int D = p.D, nchunk = D >> 2;
+    const IO *__restrict__ Y = static_cast<const IO *>(p.y);
+    const IO *__restrict__ Z = static_cast<const IO *>(p.z);
+    const IO *__restrict__ G = static_cast<const IO *>(p.dout);
+    IO *__restrict__ DY = static_cast<IO *>(p.dy);
+    IO *__restrict__ DZ = static_cast<IO *>(p.dz);
+    f4 g[K], b[K], ag[K], ab[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = lane + 64 * k;
+        g[k] = c < nchunk ? ld4(p.gamma + 4 * c) : f4{0, 0, 0, 0};
+        b[k] = c < nchunk ? ld4(p.beta + 4 * c) : f4{0, 0, 0, 0};
+        ag[k] = f4{0, 0, 0, 0};
+        ab[k] = f4{0, 0, 0, 0};
+    }
+    const float invD = 1.0f / (float)D;
+    for (long long r = wave0; r < p.rows; r += nwaves) {
+        const float mu = p.mean[r], rstd = p.rstd[r];
+        f4 nh[K], dn[K];
+        float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + 64 * k;
+            nh[k] = f4{0, 0, 0, 0};
+            dn[k] = f4{0, 0, 0, 0};
+            if (c < nchunk) {
+                const f4 yv = ld4(Y + r * D + 4 * c), zv = ld4(Z + r * p.ldz + 4 * c), gv = ld4(G + r * D + 4 * c);
+                f4 dzv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n = (yv[e] - mu) * rstd;
+                    const float v = n * g[k][e] + b[k][e];
+                    const float zz = zv[e], sg = sigmoidf_fast(zz);
+                    const float dv = gv[e] * (zz * sg);
+                    dzv[e] = gv[e] * v * (sg * (1.0f + zz * (1.0f - sg)));
+                    ag[k][e] += dv * n;
+                    ab[k][e] += dv;
+                    const float d = dv * g[k][e];
+                    nh[k][e] = n;
+                    dn[k][e] = d;
+                    s1 += d;
+                    s2 += d * n;
+                }
+                st4(DZ + r * p.lddz + 4 * c, dzv);
+            }
+        }
+        const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + 64 * k;
+            if (c < nchunk) {
+                f4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rstd * (dn[k][e] - m1 - nh[k][e] * m2);
+                st4(DY + r * D + 4 * c, o);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int c = lane + 64 * k;
+        if (c < nchunk) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                atomicAdd(p.dgamma + 4 * c + e, ag[k][e]);
+                atomicAdd(p.dbeta + 4 * c + e, ab[k][e]);
+            }
+        }
+    }
+}
+
+int check(const NormGateParams &p, int dtype, const char *name) {
+    if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("%s: unknown dtype %d", name, dtype); return -1; }
+    if (p.rows <= 0 || p.D <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
+    if (p.D % 4 || p.D > 256 * MAXK) { ss2d_set_error("%s: D %d must be a multiple of 4 and <= %d", name, p.D, 256 * MAXK); return -4; }
+    if (p.ldz < p.D || p.ldz % 4) { ss2d_set_error("%s: ldz %d must be >= D and a multiple of 4", name, p.ldz); return -4; }
+    return 0;
+}
+
+template <typename IO>
+void launch(bool bwd, const NormGateParams &p, hipStream_t s) {
+    const int K = (p.D / 4 + 63) / 64;
+    long long nwg = (p.rows + 3) / 4;
+    const long long cap = bwd ? 2048 : 8192;   // backward: fewer, longer waves keep the dgamma/dbeta atomics small
+    if (nwg > cap) nwg = cap;
+    const dim3 grid((unsigned)nwg), block(256);
+#define SS2D_NG(KK)                                                                                          \
+    if (bwd) hipLaunchKernelGGL((normgate_bwd_kernel<KK, IO>), grid, block, 0, s, p);                        \
+    else hipLaunchKernelGGL((normgate_fwd_kernel<KK, IO>), grid, block, 0, s, p);
+    switch (K) {
+        case 1: SS2D_NG(1) break;
+        case 2: SS2D_NG(2) break;
+        case 3: SS2D_NG(3) break;
+        case 4: SS2D_NG(4) break;
+        case 5: SS2D_NG(5) break;
+        default: SS2D_NG(6) break;
+    }
+#undef SS2D_NG
+}
+
+}  // namespace
+
+extern "C" int ss2d_outnorm_gate_fwd(int dtype, const void *y, const void *z, const float *gamma, const float *beta,
+                                     void *out, float *mean, float *rstd, long long rows, int D, int ldz, float eps,
+                                     void *stream) {
+    NormGateParams p{};
+    if (!y || !z || !gamma || !beta || !out) { ss2d_set_error("outnorm_gate_fwd: null pointer"); return -2; }
+    if ((mean == nullptr) != (rstd == nullptr)) { ss2d_set_error("outnorm_gate_fwd: mean and rstd go together"); return -2; }
+    p.y = y; p.z = z; p.gamma = gamma; p.beta = beta; p.out = out; p.mean = mean; p.rstd = rstd;
+    p.rows = rows; p.D = D; p.ldz = ldz; p.eps = eps;
+    int rc = check(p, dtype, "outnorm_gate_fwd");
+    if (rc) return rc;
+    if (dtype == SS2D_DTYPE_BF16) launch<bf16>(false, p, (hipStream_t)stream); else launch<float>(false, p, (hipStream_t)stream);
+    rc = (int)hipGetLastError();
+    if (rc) ss2d_set_error("outnorm_gate_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
+extern "C" int ss2d_outnorm_gate_bwd(int dtype, const void *dout, const void *y, const void *z, const float *gamma,
+                                     const float *beta, const float *mean, const float *rstd, void *dy, void *dz,
+                                     float *dgamma, float *dbeta, long long rows, int D, int ldz, int lddz,
+                                     void *stream) {
+    NormGateParams p{};
+    if (!dout || !y || !z || !gamma || !beta || !mean || !rstd || !dy || !dz || !dgamma || !dbeta) {
+        ss2d_set_error("outnorm_gate_bwd: null pointer"); return -2; }
+    p.dout = dout; p.y = y; p.z = z; p.gamma = gamma; p.beta = beta; p.mean = const_cast<float *>(mean);
+    p.rstd = const_cast<float *>(rstd); p.dy = dy; p.dz = dz; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.rows = rows; p.D = D; p.ldz = ldz; p.lddz = lddz;
+    int rc = check(p, dtype, "outnorm_gate_bwd");
+    if (rc) return rc;
+    if (lddz < D || lddz % 4) { ss2d_set_error("outnorm_gate_bwd: lddz %d must be >= D and a multiple of 4", lddz); return -4; }
+    if (dtype == SS2D_DTYPE_BF16) launch<bf16>(true, p, (hipStream_t)stream); else launch<float>(true, p, (hipStream_t)stream);
+    rc = (int)hipGetLastError();
+    if (rc) ss2d_set_error("outnorm_gate_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import selective_scan_fn
-from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_nobias
+from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_nobias, outnorm_gate
 
 
 class DropPath(nn.Module):
@@ -120,7 +120,11 @@ class SS2D(nn.Module):
 
     # ---- mamba_sys.py:396-461
     def forward_corev0(self, x: torch.Tensor):
-        """x (B, D, H, W) -> (B, H, W, D), normalised."""
+        """x (B, D, H, W) -> (B, H, W, D), normalised (the reference's swappable `forward_core`)."""
+        return self.out_norm(self._scan_core(x)).to(x.dtype)
+
+    def _scan_core(self, x: torch.Tensor):
+        """forward_corev0 up to (not including) out_norm: x (B, D, H, W) -> merged y (B, H, W, D)."""
         B, D, H, W = x.shape
         L, K, N, R = H * W, 4, self.d_state, self.dt_rank
         xs = cross_scan(x)                                                        # (B, 4, D, L)
@@ -140,17 +144,20 @@ class SS2D(nn.Module):
             self.Ds.float().view(-1), z=None, delta_bias=self.dt_projs_bias.float().view(-1),
             delta_softplus=True, return_last_state=False)
         assert out_y.dtype == (torch.bfloat16 if (self.bf16_scan_io and xs.dtype == torch.bfloat16) else torch.float32)
-        y = cross_merge(out_y.view(B, K, D, L), H, W, channel_last=True)         # (B, H, W, D)
-        return self.out_norm(y).to(x.dtype)
+        return cross_merge(out_y.view(B, K, D, L), H, W, channel_last=True)      # (B, H, W, D)
 
     # ---- mamba_sys.py:552-565
     def forward(self, x: torch.Tensor, **kwargs):
         D = self.d_inner
         xz = linear_nobias(x, self.in_proj.weight) if self.in_proj.bias is None else self.in_proj(x)   # (B, H, W, 2D)
-        z = xz[..., D:]
-        xc = dwconv3x3_silu(xz[..., :D], self.conv2d.weight, self.conv2d.bias, channel_last_in=True)
-        y = self.forward_core(xc)
-        y = y * F.silu(z)
+        xh, z = torch.split(xz, D, dim=-1)     # views; split's backward is one cat instead of two zero-fills + add
+        xc = dwconv3x3_silu(xh, self.conv2d.weight, self.conv2d.bias, channel_last_in=True)
+        if self.forward_core == self.forward_corev0 and isinstance(self.out_norm, nn.LayerNorm):
+            # out_norm, SiLU(z) and the product in one kernel (:452 + :561)
+            y = outnorm_gate(self._scan_core(xc), z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
+        else:
+            y = self.forward_core(xc)
+            y = y * F.silu(z)
         out = linear_nobias(y, self.out_proj.weight) if self.out_proj.bias is None else self.out_proj(y)
         if self.dropout is not None:
             out = self.dropout(out)

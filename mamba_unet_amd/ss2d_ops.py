@@ -200,3 +200,60 @@ def linear_nobias(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     if x.is_cuda and rows >= 32 * min(weight.shape) and not _os.environ.get("SS2D_NO_WGRAD"):   # env: A/B switch
         return _LinearNoBias.apply(x, weight)
     return torch.nn.functional.linear(x, weight)
+
+
+class _OutNormGate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, z, gamma, beta, eps):
+        _need_gpu(y, "outnorm_gate")
+        D = y.shape[-1]
+        io, code = _io(y)
+        y2 = y.reshape(-1, D)
+        y2 = y2 if y2.is_contiguous() else y2.contiguous()
+        z2 = z.to(io)
+        rows = y2.shape[0]
+        # z may be the second half of xz: unit channel stride, one constant token stride
+        zs = z2.reshape(rows, D) if z2.is_contiguous() else z2
+        if not z2.is_contiguous():
+            tok = z2.stride(-2)
+            ok = z2.stride(-1) == 1 and tok % 4 == 0 and all(z2.stride(i) == z2.stride(i + 1) * z2.shape[i + 1] for i in range(z2.dim() - 2))
+            if ok and z2.data_ptr() % 16 == 0:
+                ldz = tok
+            else:
+                zs, ldz = z2.contiguous().reshape(rows, D), D
+        if z2.is_contiguous():
+            ldz = D
+        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        out = torch.empty((rows, D), device=y.device, dtype=io)
+        mean = torch.empty(rows, device=y.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(y.device):
+            rc = _lib.load().ss2d_outnorm_gate_fwd(code, _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32), _lib.ptr(b32),
+                                                   _lib.ptr(out), _lib.ptr(mean), _lib.ptr(rstd), rows, D, ldz,
+                                                   float(eps), _stream())
+        _lib.check(rc, "ss2d_outnorm_gate_fwd")
+        ctx.save_for_backward(y2, zs, g32, b32, mean, rstd)
+        ctx.meta = (code, rows, D, ldz, y.shape, z.shape, y.dtype, z.dtype, gamma.dtype, beta.dtype)
+        return out.view(y.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y2, zs, g32, b32, mean, rstd = ctx.saved_tensors
+        code, rows, D, ldz, yshape, zshape, ydt, zdt, gdt, bdt = ctx.meta
+        g = dout.reshape(rows, D).to(y2.dtype)
+        g = g if g.is_contiguous() else g.contiguous()
+        dy = torch.empty_like(y2)
+        dz = torch.empty((rows, D), device=g.device, dtype=y2.dtype)
+        dg, db = torch.zeros_like(g32), torch.zeros_like(b32)
+        with torch.cuda.device(g.device):
+            rc = _lib.load().ss2d_outnorm_gate_bwd(code, _lib.ptr(g), _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32),
+                                                   _lib.ptr(b32), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dy),
+                                                   _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), rows, D, ldz, D, _stream())
+        _lib.check(rc, "ss2d_outnorm_gate_bwd")
+        return dy.view(yshape).to(ydt), dz.view(zshape).to(zdt), dg.to(gdt), db.to(bdt), None
+
+
+def outnorm_gate(y: torch.Tensor, z: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """LayerNorm over the last axis of y (weight, bias, eps) times SiLU(z), fused (mamba_sys.py:452 + :561).
+    z may be a channel slice of a wider tensor (the z half of xz).  Output has y's dtype."""
+    return _OutNormGate.apply(y, z, weight, bias, eps)

@@ -165,3 +165,33 @@ def test_linear_nobias_matches_f_linear():
     yr.backward(g.double())
     assert rel_l2(y.detach().cpu(), yr.detach().cpu()) < 1e-5
     assert rel_l2(x.grad.cpu(), xr.grad.cpu()) < 1e-5 and rel_l2(w.grad.cpu(), wr.grad.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("rows_shape,D,dtype", [((2, 5, 7), 192, torch.float32), ((1, 14, 14), 768, torch.float32),
+                                                 ((3, 7, 7), 1536, torch.float32), ((777,), 20, torch.float32),
+                                                 ((2, 28, 28), 384, torch.bfloat16), ((2, 9, 9), 1536, torch.bfloat16)])
+def test_outnorm_gate_fused(rows_shape, D, dtype):
+    """LayerNorm(D)(y) * SiLU(z) fused fwd/bwd against torch in fp64; z is the second half of a wider tensor."""
+    from mamba_unet_amd import outnorm_gate
+    gen = torch.Generator().manual_seed(D)
+    y = (torch.randn(*rows_shape, D, generator=gen) * 2 + 0.3).to(dtype)
+    xz = torch.randn(*rows_shape, 2 * D, generator=gen).to(dtype)
+    w = torch.rand(D, generator=gen) + 0.5
+    b = torch.randn(D, generator=gen) * 0.1
+    go = torch.randn(*rows_shape, D, generator=gen).to(dtype)
+    yr, xzr = y.double().requires_grad_(True), xz.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(yr, (D,), wr, br, 1e-5) * torch.nn.functional.silu(xzr[..., D:])
+    ref.backward(go.double())
+    yd, xzd = y.cuda().requires_grad_(True), xz.cuda().requires_grad_(True)
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = outnorm_gate(yd, xzd[..., D:], wd, bd, 1e-5)
+    assert out.dtype == dtype and out.shape == y.shape
+    out.backward(go.cuda())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(out.detach().float().cpu(), ref.detach()) < tol
+    assert rel_l2(yd.grad.float().cpu(), yr.grad) < tol
+    assert rel_l2(xzd.grad[..., D:].float().cpu(), xzr.grad[..., D:]) < tol
+    assert float(xzd.grad[..., :D].abs().max()) == 0.0
+    ptol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(wd.grad.cpu(), wr.grad) < ptol and rel_l2(bd.grad.cpu(), br.grad) < ptol
