@@ -85,10 +85,13 @@ __global__ __launch_bounds__(256) void normgate_fwd_kernel(const NormGateParams 
     }
 }
 
-template <int K, typename IO>
-__global__ __launch_bounds__(256) void normgate_bwd_kernel(const NormGateParams p) {
+template <int K, int NWV, typename IO>
+__global__ __launch_bounds__(NWV * 64) void normgate_bwd_kernel(const NormGateParams p) {
+    __shared__ float red[2][K * 256];   // workgroup sums of dgamma / dbeta
     const int lane = threadIdx.x & 63;
-    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    const long long wave0 = (long long)blockIdx.x * NWV + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * NWV;
+    for (int i = threadIdx.x; i < 2 * K * 256; i += NWV * 64) (&red[0][0])[i] = 0.0f;
+    __syncthreads();
     const int D = p.D, nchunk = D >> 2;
     const IO *__restrict__ Y = static_cast<const IO *>(p.y);
     const IO *__restrict__ Z = static_cast<const IO *>(p.z);
@@ -147,16 +150,23 @@ __global__ __launch_bounds__(256) void normgate_bwd_kernel(const NormGateParams 
             }
         }
     }
+    // per-lane column sums -> workgroup sums in LDS -> one global atomic per column and workgroup (at most 256
+    // workgroups: thousands of same-address global atomics would serialise in L2)
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int c = lane + 64 * k;
         if (c < nchunk) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                atomicAdd(p.dgamma + 4 * c + e, ag[k][e]);
-                atomicAdd(p.dbeta + 4 * c + e, ab[k][e]);
+                atomicAdd(&red[0][4 * c + e], ag[k][e]);
+                atomicAdd(&red[1][4 * c + e], ab[k][e]);
             }
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += NWV * 64) {
+        atomicAdd(p.dgamma + i, red[0][i]);
+        atomicAdd(p.dbeta + i, red[1][i]);
     }
 }
 
@@ -171,22 +181,33 @@ int check(const NormGateParams &p, int dtype, const char *name) {
 template <typename IO>
 void launch(bool bwd, const NormGateParams &p, hipStream_t s) {
     const int K = (p.D / 4 + 63) / 64;
-    long long nwg = (p.rows + 3) / 4;
-    const long long cap = bwd ? 2048 : 8192;   // backward: fewer, longer waves keep the dgamma/dbeta atomics small
-    if (nwg > cap) nwg = cap;
-    const dim3 grid((unsigned)nwg), block(256);
-#define SS2D_NG(KK)                                                                                          \
-    if (bwd) hipLaunchKernelGGL((normgate_bwd_kernel<KK, IO>), grid, block, 0, s, p);                        \
-    else hipLaunchKernelGGL((normgate_fwd_kernel<KK, IO>), grid, block, 0, s, p);
-    switch (K) {
-        case 1: SS2D_NG(1) break;
-        case 2: SS2D_NG(2) break;
-        case 3: SS2D_NG(3) break;
-        case 4: SS2D_NG(4) break;
-        case 5: SS2D_NG(5) break;
-        default: SS2D_NG(6) break;
+    if (!bwd) {
+        long long nwg = (p.rows + 3) / 4;
+        if (nwg > 8192) nwg = 8192;
+        const dim3 grid((unsigned)nwg), block(256);
+        switch (K) {
+            case 1: hipLaunchKernelGGL((normgate_fwd_kernel<1, IO>), grid, block, 0, s, p); break;
+            case 2: hipLaunchKernelGGL((normgate_fwd_kernel<2, IO>), grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL((normgate_fwd_kernel<3, IO>), grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL((normgate_fwd_kernel<4, IO>), grid, block, 0, s, p); break;
+            case 5: hipLaunchKernelGGL((normgate_fwd_kernel<5, IO>), grid, block, 0, s, p); break;
+            default: hipLaunchKernelGGL((normgate_fwd_kernel<6, IO>), grid, block, 0, s, p); break;
+        }
+        return;
     }
-#undef SS2D_NG
+    // backward: at most 256 workgroups (one per CU); 16 waves each where the register budget allows it (K <= 2)
+    const int nwv = K <= 2 ? 16 : 4;
+    long long nwg = (p.rows + nwv - 1) / nwv;
+    if (nwg > 256) nwg = 256;
+    const dim3 grid((unsigned)nwg), block(nwv * 64);
+    switch (K) {
+        case 1: hipLaunchKernelGGL((normgate_bwd_kernel<1, 16, IO>), grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((normgate_bwd_kernel<2, 16, IO>), grid, block, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((normgate_bwd_kernel<3, 4, IO>), grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((normgate_bwd_kernel<4, 4, IO>), grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL((normgate_bwd_kernel<5, 4, IO>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((normgate_bwd_kernel<6, 4, IO>), grid, block, 0, s, p); break;
+    }
 }
 
 }  // namespace
