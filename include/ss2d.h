@@ -104,6 +104,17 @@ int ss2d_outnorm_gate_bwd(int dtype, const void *dout, const void *y, const void
                           const float *beta, const float *mean, const float *rstd, void *dy, void *dz, float *dgamma,
                           float *dbeta, long long rows, int D, int ldz, int lddz, void *stream);
 
+/* LayerNorm over the last axis, eps inside the sqrt: the `ln_1` of VSSBlock (mamba_sys.py:573-585) and the norms
+ * of PatchMerging2D / PatchExpand / FinalPatchExpand_X4 (:196, :226, :249).  x, dx: (rows, D) in `in_dtype`;
+ * out, dout: (rows, D) in `out_dtype` (fp32->fp32, bf16->bf16, or fp32->bf16: normalise the fp32 residual stream
+ * straight into the bf16 operand of the next GEMM).  mean/rstd (rows, fp32) written by _fwd when non-NULL, read by
+ * _bwd.  dgamma, dbeta (D, fp32) ACCUMULATED INTO with float atomics: caller zero-fills.  D % 4 == 0, D <= 1536. */
+int ss2d_layernorm_fwd(int in_dtype, int out_dtype, const void *x, const float *gamma, const float *beta, void *out,
+                       float *mean, float *rstd, long long rows, int D, float eps, void *stream);
+int ss2d_layernorm_bwd(int in_dtype, int out_dtype, const void *dout, const void *x, const float *gamma,
+                       const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta, long long rows,
+                       int D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

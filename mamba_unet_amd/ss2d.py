@@ -20,7 +20,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import selective_scan_fn
-from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, linear_nobias, outnorm_gate
+from .ss2d_ops import apply_norm, cross_merge, cross_scan, dwconv3x3_silu, linear_nobias, outnorm_gate
 
 
 class DropPath(nn.Module):
@@ -176,7 +176,7 @@ class VSSBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, input: torch.Tensor):
-        return input + self.drop_path(self.self_attention(self.ln_1(input)))
+        return input + self.drop_path(self.self_attention(apply_norm(self.ln_1, input)))
 
 
 def _burn_out_proj_rng(module: nn.Module):

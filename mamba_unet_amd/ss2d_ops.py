@@ -257,3 +257,69 @@ def outnorm_gate(y: torch.Tensor, z: torch.Tensor, weight: torch.Tensor, bias: t
     """LayerNorm over the last axis of y (weight, bias, eps) times SiLU(z), fused (mamba_sys.py:452 + :561).
     z may be a channel slice of a wider tensor (the z half of xz).  Output has y's dtype."""
     return _OutNormGate.apply(y, z, weight, bias, eps)
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _need_gpu(x, "layer_norm")
+        D = x.shape[-1]
+        io, code = _io(x)
+        x2 = x.to(io).reshape(-1, D)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        # under bf16 autocast the consumer is a bf16 GEMM: write bf16 directly (torch would return fp32 and cast)
+        out_bf16 = io == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        ocode, odt = (_BF16, torch.bfloat16) if out_bf16 else (_F32, torch.float32)
+        rows = x2.shape[0]
+        g32, b32 = weight.float().contiguous(), bias.float().contiguous()
+        out = torch.empty((rows, D), device=x.device, dtype=odt)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().ss2d_layernorm_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(out),
+                                                _lib.ptr(mean), _lib.ptr(rstd), rows, D, float(eps), _stream())
+        _lib.check(rc, "ss2d_layernorm_fwd")
+        ctx.save_for_backward(x2, g32, mean, rstd)
+        ctx.meta = (code, ocode, odt, rows, D, x.shape, x.dtype, weight.dtype, bias.dtype)
+        return out.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, g32, mean, rstd = ctx.saved_tensors
+        code, ocode, odt, rows, D, xshape, xdt, wdt, bdt = ctx.meta
+        g = dout.reshape(rows, D).to(odt)
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty_like(x2)
+        dg, db = torch.zeros_like(g32), torch.zeros_like(g32)
+        with torch.cuda.device(g.device):
+            rc = _lib.load().ss2d_layernorm_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
+                                                _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), rows, D, _stream())
+        _lib.check(rc, "ss2d_layernorm_bwd")
+        return dx.view(xshape).to(xdt), dg.to(wdt), db.to(bdt), None
+
+
+def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """F.layer_norm(x, (D,), weight, bias, eps) over the last axis on the HIP kernel (D % 4 == 0, D <= 1536, GPU
+    tensors); anything else goes to torch.  Under bf16 autocast the result is bf16."""
+    D = x.shape[-1]
+    if x.is_cuda and D % 4 == 0 and D <= 1536 and weight is not None and bias is not None:
+        return _LayerNorm.apply(x, weight, bias, eps)
+    return torch.nn.functional.layer_norm(x, (D,), weight, bias, eps)
+
+
+class LayerNorm(torch.nn.LayerNorm):
+    """nn.LayerNorm (same parameters / state-dict keys) whose forward runs the HIP kernel."""
+
+    def forward(self, x):
+        if len(self.normalized_shape) == 1 and self.elementwise_affine and self.bias is not None:
+            return layer_norm(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
+def apply_norm(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """module(x), on the HIP LayerNorm kernel when `module` is a plain nn.LayerNorm over the last axis (the modules
+    stay nn.LayerNorm so the reference's constructor arguments, init and state-dict keys are untouched)."""
+    if type(module) is torch.nn.LayerNorm and len(module.normalized_shape) == 1 and module.elementwise_affine \
+            and module.bias is not None and x.is_cuda:
+        return layer_norm(x, module.weight, module.bias, module.eps)
+    return module(x)

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .ss2d import VSSLayer, VSSLayer_up
+from .ss2d_ops import apply_norm
 
 
 def _pixel_unshuffle_cl(x: torch.Tensor, p: int) -> torch.Tensor:
@@ -38,7 +39,7 @@ class PatchEmbed2D(nn.Module):
 
     def forward(self, x):
         x = self.proj(x).permute(0, 2, 3, 1)
-        return self.norm(x) if self.norm is not None else x
+        return apply_norm(self.norm, x) if self.norm is not None else x
 
 
 class PatchMerging2D(nn.Module):
@@ -57,7 +58,7 @@ class PatchMerging2D(nn.Module):
             print(f"Warning, x.shape {x.shape} is not match even ===========", flush=True)
         parts = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
         x = torch.cat(parts, dim=-1).view(B, h2, w2, 4 * C)
-        return self.reduction(self.norm(x))
+        return self.reduction(apply_norm(self.norm, x))
 
 
 class PatchExpand(nn.Module):
@@ -70,7 +71,7 @@ class PatchExpand(nn.Module):
         self.norm = norm_layer(dim // dim_scale)
 
     def forward(self, x):
-        return self.norm(_pixel_unshuffle_cl(self.expand(x), 2))
+        return apply_norm(self.norm, _pixel_unshuffle_cl(self.expand(x), 2))
 
 
 class FinalPatchExpand_X4(nn.Module):
@@ -84,7 +85,7 @@ class FinalPatchExpand_X4(nn.Module):
         self.norm = norm_layer(self.output_dim)
 
     def forward(self, x):
-        return self.norm(_pixel_unshuffle_cl(self.expand(x), self.dim_scale))
+        return apply_norm(self.norm, _pixel_unshuffle_cl(self.expand(x), self.dim_scale))
 
 
 class VSSM(nn.Module):
@@ -155,14 +156,14 @@ class VSSM(nn.Module):
         for layer in self.layers:
             skips.append(x)
             x = layer(x)
-        return self.norm(x), skips
+        return apply_norm(self.norm, x), skips
 
     def forward_up_features(self, x, x_downsample):
         for i, up in enumerate(self.layers_up):
             if i > 0:
                 x = self.concat_back_dim[i](torch.cat([x, x_downsample[3 - i]], dim=-1))
             x = up(x)
-        return self.norm_up(x)
+        return apply_norm(self.norm_up, x)
 
     def up_x4(self, x):
         if self.final_upsample == "expand_first":

@@ -195,3 +195,28 @@ def test_outnorm_gate_fused(rows_shape, D, dtype):
     assert float(xzd.grad[..., :D].abs().max()) == 0.0
     ptol = 2e-5 if dtype == torch.float32 else 1e-2
     assert rel_l2(wd.grad.cpu(), wr.grad) < ptol and rel_l2(bd.grad.cpu(), br.grad) < ptol
+
+
+@pytest.mark.parametrize("rows_shape,D,dtype,autocast", [((2, 56, 56), 96, torch.float32, False), ((1, 14, 14), 768, torch.float32, False),
+                                                          ((3, 7, 7), 1536, torch.float32, False), ((777,), 20, torch.float32, False),
+                                                          ((2, 28, 28), 384, torch.bfloat16, False), ((2, 28, 28), 192, torch.float32, True)])
+def test_layer_norm_kernel(rows_shape, D, dtype, autocast):
+    """HIP LayerNorm fwd/bwd against torch fp64; under bf16 autocast fp32 input -> bf16 output, fp32 dx."""
+    from mamba_unet_amd import layer_norm
+    gen = torch.Generator().manual_seed(D + 1)
+    x = (torch.randn(*rows_shape, D, generator=gen) * 1.7 - 0.2).to(dtype)
+    w, b = torch.rand(D, generator=gen) + 0.5, torch.randn(D, generator=gen) * 0.1
+    go = torch.randn(*rows_shape, D, generator=gen).to(torch.bfloat16 if autocast else dtype)
+    xr, wr, br = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-5)
+    ref.backward(go.double())
+    xd, wd, bd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        out = layer_norm(xd, wd, bd, 1e-5)
+    assert out.dtype == (torch.bfloat16 if autocast else dtype) and xd.dtype == dtype
+    out.backward(go.cuda())
+    assert xd.grad.dtype == dtype
+    tol = 1e-5 if (dtype == torch.float32 and not autocast) else 1e-2
+    assert rel_l2(out.detach().float().cpu(), ref.detach()) < tol
+    assert rel_l2(xd.grad.float().cpu(), xr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert rel_l2(wd.grad.cpu(), wr.grad) < 2e-5 and rel_l2(bd.grad.cpu(), br.grad) < 2e-5
