@@ -20,7 +20,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import selective_scan_fn
-from .ss2d_ops import apply_norm, cross_merge, cross_scan, dwconv3x3_silu, linear_nobias, outnorm_gate
+from .ss2d_ops import apply_linear, apply_norm, cross_merge, cross_scan, dwconv3x3_silu, outnorm_gate
 
 
 class DropPath(nn.Module):
@@ -149,7 +149,7 @@ class SS2D(nn.Module):
     # ---- mamba_sys.py:552-565
     def forward(self, x: torch.Tensor, **kwargs):
         D = self.d_inner
-        xz = linear_nobias(x, self.in_proj.weight) if self.in_proj.bias is None else self.in_proj(x)   # (B, H, W, 2D)
+        xz = apply_linear(self.in_proj, x)                                         # (B, H, W, 2D)
         xh, z = torch.split(xz, D, dim=-1)     # views; split's backward is one cat instead of two zero-fills + add
         xc = dwconv3x3_silu(xh, self.conv2d.weight, self.conv2d.bias, channel_last_in=True)
         if self.forward_core == self.forward_corev0 and isinstance(self.out_norm, nn.LayerNorm):
@@ -158,7 +158,7 @@ class SS2D(nn.Module):
         else:
             y = self.forward_core(xc)
             y = y * F.silu(z)
-        out = linear_nobias(y, self.out_proj.weight) if self.out_proj.bias is None else self.out_proj(y)
+        out = apply_linear(self.out_proj, y)
         if self.dropout is not None:
             out = self.dropout(out)
         return out

@@ -168,21 +168,22 @@ def linear_wgrad(grad_out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
     return dw
 
 
-class _LinearNoBias(torch.autograd.Function):
-    """y = x W^T for the projections whose token axis dwarfs both feature axes: forward and dX stay on
-    hipBLASLt (F.linear / matmul, good shapes), dW goes to the split-token MFMA kernel."""
+class _Linear(torch.autograd.Function):
+    """y = x W^T (+ b) for the Linears whose token axis dwarfs both feature axes: forward and dX stay on
+    hipBLASLt (F.linear / matmul, good shapes), dW goes to the split-token MFMA kernel, db is a column sum."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, bias):
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype("cuda")
             x, w = x.to(dt), weight.to(dt)
+            b = None if bias is None else bias.to(dt)
         else:
-            w = weight
+            w, b = weight, bias
         ctx.save_for_backward(x, w)
-        ctx.w_dtype = weight.dtype
+        ctx.w_dtype, ctx.b_dtype = weight.dtype, None if bias is None else bias.dtype
         with torch.autocast("cuda", enabled=False):
-            return torch.nn.functional.linear(x, w)
+            return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, g):
@@ -190,16 +191,30 @@ class _LinearNoBias(torch.autograd.Function):
         g = g.to(x.dtype)
         dx = torch.matmul(g, w) if ctx.needs_input_grad[0] else None
         dw = linear_wgrad(g, x).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
-        return dx, dw
+        db = None
+        if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
+            db = g.reshape(-1, g.shape[-1]).sum(0, dtype=torch.float32).to(ctx.b_dtype)
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    """F.linear(x, weight, bias) with the weight gradient on the MFMA split-token kernel when the token axis is
+    long (>= 32x the smaller feature axis: stages 0 and 1 of MambaUNet); plain F.linear otherwise."""
+    rows = x.numel() // x.shape[-1]
+    if x.is_cuda and rows >= 32 * min(weight.shape) and not _os.environ.get("SS2D_NO_WGRAD"):   # env: A/B switch
+        return _Linear.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
 
 
 def linear_nobias(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    """F.linear(x, weight) with the weight gradient on the MFMA split-token kernel when the token axis is long
-    (>= 32x the smaller feature axis: stages 0 and 1 of MambaUNet); plain F.linear otherwise."""
-    rows = x.numel() // x.shape[-1]
-    if x.is_cuda and rows >= 32 * min(weight.shape) and not _os.environ.get("SS2D_NO_WGRAD"):   # env: A/B switch
-        return _LinearNoBias.apply(x, weight)
-    return torch.nn.functional.linear(x, weight)
+    return linear(x, weight, None)
+
+
+def apply_linear(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """module(x) for an nn.Linear (or nn.Identity) through `linear` above; the module and its parameters are untouched."""
+    if type(module) is torch.nn.Linear:
+        return linear(x, module.weight, module.bias)
+    return module(x)
 
 
 class _OutNormGate(torch.autograd.Function):

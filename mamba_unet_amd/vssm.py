@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .ss2d import VSSLayer, VSSLayer_up
-from .ss2d_ops import apply_norm
+from .ss2d_ops import apply_linear, apply_norm
 
 
 def _pixel_unshuffle_cl(x: torch.Tensor, p: int) -> torch.Tensor:
@@ -58,7 +58,7 @@ class PatchMerging2D(nn.Module):
             print(f"Warning, x.shape {x.shape} is not match even ===========", flush=True)
         parts = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
         x = torch.cat(parts, dim=-1).view(B, h2, w2, 4 * C)
-        return self.reduction(apply_norm(self.norm, x))
+        return apply_linear(self.reduction, apply_norm(self.norm, x))
 
 
 class PatchExpand(nn.Module):
@@ -71,7 +71,7 @@ class PatchExpand(nn.Module):
         self.norm = norm_layer(dim // dim_scale)
 
     def forward(self, x):
-        return apply_norm(self.norm, _pixel_unshuffle_cl(self.expand(x), 2))
+        return apply_norm(self.norm, _pixel_unshuffle_cl(apply_linear(self.expand, x), 2))
 
 
 class FinalPatchExpand_X4(nn.Module):
@@ -85,7 +85,7 @@ class FinalPatchExpand_X4(nn.Module):
         self.norm = norm_layer(self.output_dim)
 
     def forward(self, x):
-        return apply_norm(self.norm, _pixel_unshuffle_cl(self.expand(x), self.dim_scale))
+        return apply_norm(self.norm, _pixel_unshuffle_cl(apply_linear(self.expand, x), self.dim_scale))
 
 
 class VSSM(nn.Module):
@@ -161,7 +161,7 @@ class VSSM(nn.Module):
     def forward_up_features(self, x, x_downsample):
         for i, up in enumerate(self.layers_up):
             if i > 0:
-                x = self.concat_back_dim[i](torch.cat([x, x_downsample[3 - i]], dim=-1))
+                x = apply_linear(self.concat_back_dim[i], torch.cat([x, x_downsample[3 - i]], dim=-1))
             x = up(x)
         return apply_norm(self.norm_up, x)
 

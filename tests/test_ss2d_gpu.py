@@ -220,3 +220,20 @@ def test_layer_norm_kernel(rows_shape, D, dtype, autocast):
     assert rel_l2(out.detach().float().cpu(), ref.detach()) < tol
     assert rel_l2(xd.grad.float().cpu(), xr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
     assert rel_l2(wd.grad.cpu(), wr.grad) < 2e-5 and rel_l2(bd.grad.cpu(), br.grad) < 2e-5
+
+
+def test_linear_with_bias_matches_f_linear():
+    from mamba_unet_amd.ss2d_ops import linear
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 56, 56, 192, generator=gen).cuda().requires_grad_(True)
+    w = (torch.randn(96, 192, generator=gen) * 0.05).cuda().requires_grad_(True)
+    b = torch.randn(96, generator=gen).cuda().requires_grad_(True)
+    g = torch.randn(2, 56, 56, 96, generator=gen).cuda()
+    y = linear(x, w, b)
+    y.backward(g)
+    xr, wr, br = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(g.double())
+    assert rel_l2(y.detach().cpu(), yr.detach().cpu()) < 1e-5
+    for a, r in ((x, xr), (w, wr), (b, br)):
+        assert rel_l2(a.grad.cpu(), r.grad.cpu()) < 1e-5
