@@ -22,23 +22,28 @@ struct LNParams {
     float eps;
 };
 
+// sum over the LW (64 or 32) lanes that share a row
+template <int LW>
 __device__ __forceinline__ float wave_sum_ln(float v) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    for (int o = LW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 
-template <int K, typename TI, typename TO>
+// LW = lanes per row: 64, or 32 (two rows per wave) when a row has at most 32 four-element chunks (D <= 128)
+template <int K, int LW, typename TI, typename TO>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const LNParams p) {
-    const int lane = threadIdx.x & 63;
-    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * 4;
+    constexpr int RPW = 64 / LW;
+    const int lane = threadIdx.x & (LW - 1);
+    const long long wave0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LW);
+    const long long nwaves = (long long)gridDim.x * 4 * RPW;
     const int D = p.D, nchunk = D >> 2;
     const TI *__restrict__ X = static_cast<const TI *>(p.x);
     TO *__restrict__ O = static_cast<TO *>(p.out);
     f4 g[K], b[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int c = lane + 64 * k;
+        const int c = lane + LW * k;
         g[k] = c < nchunk ? ld4(p.gamma + 4 * c) : f4{0, 0, 0, 0};
         b[k] = c < nchunk ? ld4(p.beta + 4 * c) : f4{0, 0, 0, 0};
     }
@@ -48,35 +53,37 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LNParams p) {
         float s = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const int c = lane + 64 * k;
+            const int c = lane + LW * k;
             xv[k] = c < nchunk ? ld4(X + r * D + 4 * c) : f4{0, 0, 0, 0};
             s += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
         }
-        const float mu = wave_sum_ln(s) * invD;
+        const float mu = wave_sum_ln<LW>(s) * invD;
         float q = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const int c = lane + 64 * k;
+            const int c = lane + LW * k;
             if (c < nchunk) {
                 const f4 d = xv[k] - mu;
                 q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
             }
         }
-        const float rstd = __builtin_amdgcn_rsqf(wave_sum_ln(q) * invD + p.eps);
+        const float rstd = __builtin_amdgcn_rsqf(wave_sum_ln<LW>(q) * invD + p.eps);
         if (lane == 0 && p.mean) { p.mean[r] = mu; p.rstd[r] = rstd; }
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const int c = lane + 64 * k;
+            const int c = lane + LW * k;
             if (c < nchunk) st4(O + r * D + 4 * c, (xv[k] - mu) * rstd * g[k] + b[k]);
         }
     }
 }
 
-template <int K, int NWV, typename TI, typename TO>
+template <int K, int NWV, int LW, typename TI, typename TO>
 __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
     __shared__ float red[2][K * 256];
-    const int lane = threadIdx.x & 63;
-    const long long wave0 = (long long)blockIdx.x * NWV + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * NWV;
+    constexpr int RPW = 64 / LW;
+    const int lane = threadIdx.x & (LW - 1);
+    const long long wave0 = ((long long)blockIdx.x * NWV + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LW);
+    const long long nwaves = (long long)gridDim.x * NWV * RPW;
     for (int i = threadIdx.x; i < 2 * K * 256; i += NWV * 64) (&red[0][0])[i] = 0.0f;
     __syncthreads();
     const int D = p.D, nchunk = D >> 2;
@@ -86,7 +93,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
     f4 g[K], ag[K], ab[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int c = lane + 64 * k;
+        const int c = lane + LW * k;
         g[k] = c < nchunk ? ld4(p.gamma + 4 * c) : f4{0, 0, 0, 0};
         ag[k] = f4{0, 0, 0, 0};
         ab[k] = f4{0, 0, 0, 0};
@@ -98,7 +105,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const int c = lane + 64 * k;
+            const int c = lane + LW * k;
             nh[k] = f4{0, 0, 0, 0};
             dn[k] = f4{0, 0, 0, 0};
             if (c < nchunk) {
@@ -112,16 +119,16 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
                 s2 += (t.x + t.y) + (t.z + t.w);
             }
         }
-        const float m1 = wave_sum_ln(s1) * invD, m2 = wave_sum_ln(s2) * invD;
+        const float m1 = wave_sum_ln<LW>(s1) * invD, m2 = wave_sum_ln<LW>(s2) * invD;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const int c = lane + 64 * k;
+            const int c = lane + LW * k;
             if (c < nchunk) st4(DX + r * D + 4 * c, (dn[k] - m1 - nh[k] * m2) * rstd);
         }
     }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const int c = lane + 64 * k;
+        const int c = lane + LW * k;
         if (c < nchunk) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -139,32 +146,37 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
 
 template <typename TI, typename TO>
 void launch_ln(bool bwd, const LNParams &p, hipStream_t s) {
-    const int K = (p.D / 4 + 63) / 64;
+    const int nchunk = p.D / 4;
+    const bool half = nchunk <= 32;              // two rows per wave
+    const int K = half ? 1 : (nchunk + 63) / 64;
+    const int rpw = half ? 2 : 1;
     if (!bwd) {
-        long long nwg = (p.rows + 3) / 4;
+        long long nwg = (p.rows + 4 * rpw - 1) / (4 * rpw);
         if (nwg > 8192) nwg = 8192;
         const dim3 grid((unsigned)nwg), block(256);
+        if (half) { hipLaunchKernelGGL((ln_fwd_kernel<1, 32, TI, TO>), grid, block, 0, s, p); return; }
         switch (K) {
-            case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, TI, TO>), grid, block, 0, s, p); break;
-            case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, TI, TO>), grid, block, 0, s, p); break;
-            case 3: hipLaunchKernelGGL((ln_fwd_kernel<3, TI, TO>), grid, block, 0, s, p); break;
-            case 4: hipLaunchKernelGGL((ln_fwd_kernel<4, TI, TO>), grid, block, 0, s, p); break;
-            case 5: hipLaunchKernelGGL((ln_fwd_kernel<5, TI, TO>), grid, block, 0, s, p); break;
-            default: hipLaunchKernelGGL((ln_fwd_kernel<6, TI, TO>), grid, block, 0, s, p); break;
+            case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL((ln_fwd_kernel<3, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL((ln_fwd_kernel<4, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 5: hipLaunchKernelGGL((ln_fwd_kernel<5, 64, TI, TO>), grid, block, 0, s, p); break;
+            default: hipLaunchKernelGGL((ln_fwd_kernel<6, 64, TI, TO>), grid, block, 0, s, p); break;
         }
         return;
     }
     const int nwv = K <= 2 ? 16 : 4;
-    long long nwg = (p.rows + nwv - 1) / nwv;
+    long long nwg = (p.rows + nwv * rpw - 1) / (nwv * rpw);
     if (nwg > 256) nwg = 256;
     const dim3 grid((unsigned)nwg), block(nwv * 64);
+    if (half) { hipLaunchKernelGGL((ln_bwd_kernel<1, 16, 32, TI, TO>), grid, block, 0, s, p); return; }
     switch (K) {
-        case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 16, TI, TO>), grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 16, TI, TO>), grid, block, 0, s, p); break;
-        case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 4, TI, TO>), grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, 4, TI, TO>), grid, block, 0, s, p); break;
-        case 5: hipLaunchKernelGGL((ln_bwd_kernel<5, 4, TI, TO>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((ln_bwd_kernel<6, 4, TI, TO>), grid, block, 0, s, p); break;
+        case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 16, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 16, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 4, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, 4, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL((ln_bwd_kernel<5, 4, 64, TI, TO>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((ln_bwd_kernel<6, 4, 64, TI, TO>), grid, block, 0, s, p); break;
     }
 }
 
