@@ -130,6 +130,119 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
     }
 }
 
+// ---- vector variants: every lane moves 4 consecutive elements along the fast axis of the phase (w, h or d),
+// i.e. 16-byte (fp32) / 8-byte (bf16) global accesses; the LDS tile and its odd strides are those of the scalar
+// kernels above.  Require H % 4 == 0, W % 4 == 0 (and D % 4 == 0 on a channel-last side) and aligned pointers;
+// the host falls back to the scalar kernels otherwise (14x14 and 7x7 stages).
+__device__ __forceinline__ f4 rev4(f4 v) { return f4{v.w, v.z, v.y, v.x}; }
+
+template <bool CL, typename IO>
+__global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p) {
+    __shared__ float s[TD * SD];
+    const IO *__restrict__ in = static_cast<const IO *>(p.in);
+    IO *__restrict__ out = static_cast<IO *>(p.out);
+    int b, d0, h0, w0;
+    tile_coords(p, b, d0, h0, w0);
+    const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
+    const size_t L = (size_t)H * W;
+    if (CL) {  // 4 consecutive channels per lane
+        for (int i = tid; i < TD * TH * TW / 4; i += 256) {
+            const int d = (i & 7) * 4, pos = i >> 3, w = pos & (TW - 1), h = pos >> 4;
+            f4 v = f4{0, 0, 0, 0};
+            if (d0 + d < D && h0 + h < H && w0 + w < W) v = ld4(in + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[(d + e) * SD + h * SW + w] = v[e];
+        }
+    } else {   // 4 consecutive columns per lane
+        for (int i = tid; i < TD * TH * TW / 4; i += 256) {
+            const int w = (i & 3) * 4, h = (i >> 2) & (TH - 1), d = i >> 6;
+            f4 v = f4{0, 0, 0, 0};
+            if (d0 + d < D && h0 + h < H && w0 + w < W) v = ld4(in + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[d * SD + h * SW + w + e] = v[e];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < TD * TH * TW / 4; i += 256) {   // directions 0 and 2: runs along w
+        const int w = (i & 3) * 4, h = (i >> 2) & (TH - 1), d = i >> 6;
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            f4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = s[d * SD + h * SW + w + e];
+            const size_t pp = (size_t)(h0 + h) * W + w0 + w;
+            st4(out + (((size_t)b * 4 + 0) * D + d0 + d) * L + pp, v);
+            st4(out + (((size_t)b * 4 + 2) * D + d0 + d) * L + (L - 4 - pp), rev4(v));
+        }
+    }
+    for (int i = tid; i < TD * TH * TW / 4; i += 256) {   // directions 1 and 3: runs along h
+        const int h = (i & 3) * 4, w = (i >> 2) & (TW - 1), d = i >> 6;
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            f4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = s[d * SD + (h + e) * SW + w];
+            const size_t q = (size_t)(w0 + w) * H + h0 + h;
+            st4(out + (((size_t)b * 4 + 1) * D + d0 + d) * L + q, v);
+            st4(out + (((size_t)b * 4 + 3) * D + d0 + d) * L + (L - 4 - q), rev4(v));
+        }
+    }
+}
+
+template <bool CL, typename IO>
+__global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams p) {
+    __shared__ float s[TD * SD];
+    const IO *__restrict__ in = static_cast<const IO *>(p.in);
+    IO *__restrict__ out = static_cast<IO *>(p.out);
+    int b, d0, h0, w0;
+    tile_coords(p, b, d0, h0, w0);
+    const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
+    const size_t L = (size_t)H * W;
+    for (int i = tid; i < TD * TH * TW / 4; i += 256) {
+        const int w = (i & 3) * 4, h = (i >> 2) & (TH - 1), d = i >> 6;
+        f4 v = f4{0, 0, 0, 0};
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            const size_t pp = (size_t)(h0 + h) * W + w0 + w;
+            v = ld4(in + (((size_t)b * 4 + 0) * D + d0 + d) * L + pp) +
+                rev4(ld4(in + (((size_t)b * 4 + 2) * D + d0 + d) * L + (L - 4 - pp)));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[d * SD + h * SW + w + e] = v[e];
+    }
+    __syncthreads();
+    for (int i = tid; i < TD * TH * TW / 4; i += 256) {
+        const int h = (i & 3) * 4, w = (i >> 2) & (TW - 1), d = i >> 6;
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            const size_t q = (size_t)(w0 + w) * H + h0 + h;
+            const f4 v1 = ld4(in + (((size_t)b * 4 + 1) * D + d0 + d) * L + q);
+            const f4 v3 = rev4(ld4(in + (((size_t)b * 4 + 3) * D + d0 + d) * L + (L - 4 - q)));
+            // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[d * SD + (h + e) * SW + w] = (s[d * SD + (h + e) * SW + w] + v1[e]) + v3[e];
+        }
+    }
+    __syncthreads();
+    if (CL) {
+        for (int i = tid; i < TD * TH * TW / 4; i += 256) {
+            const int d = (i & 7) * 4, pos = i >> 3, w = pos & (TW - 1), h = pos >> 4;
+            if (d0 + d < D && h0 + h < H && w0 + w < W) {
+                f4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = s[(d + e) * SD + h * SW + w];
+                st4(out + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d, v);
+            }
+        }
+    } else {
+        for (int i = tid; i < TD * TH * TW / 4; i += 256) {
+            const int w = (i & 3) * 4, h = (i >> 2) & (TH - 1), d = i >> 6;
+            if (d0 + d < D && h0 + h < H && w0 + w < W) {
+                f4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = s[d * SD + h * SW + w + e];
+                st4(out + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w, v);
+            }
+        }
+    }
+}
+
 int run(bool merge, bool cl, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("%s: unknown dtype %d", name, dtype); return -1; }
     if (!in || !out) { ss2d_set_error("%s: null pointer", name); return -2; }
@@ -142,7 +255,17 @@ int run(bool merge, bool cl, int dtype, const void *in, void *out, int B, int D,
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)n), block(256);
     const bool h = dtype == SS2D_DTYPE_BF16;
-    if (merge) {
+    const uintptr_t amask = h ? 7 : 15;   // 4 elements
+    const bool vec = (H % 4 == 0) && (W % 4 == 0) && (!cl || D % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & amask) == 0);
+    if (vec) {
+        if (merge) {
+            if (cl) { if (h) hipLaunchKernelGGL((cross_merge_vec_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_vec_kernel<true, float>), grid, block, 0, s, p); }
+            else    { if (h) hipLaunchKernelGGL((cross_merge_vec_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_vec_kernel<false, float>), grid, block, 0, s, p); }
+        } else {
+            if (cl) { if (h) hipLaunchKernelGGL((cross_scan_vec_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_scan_vec_kernel<true, float>), grid, block, 0, s, p); }
+            else    { if (h) hipLaunchKernelGGL((cross_scan_vec_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_scan_vec_kernel<false, float>), grid, block, 0, s, p); }
+        }
+    } else if (merge) {
         if (cl) { if (h) hipLaunchKernelGGL((cross_merge_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_kernel<true, float>), grid, block, 0, s, p); }
         else    { if (h) hipLaunchKernelGGL((cross_merge_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_kernel<false, float>), grid, block, 0, s, p); }
     } else {
