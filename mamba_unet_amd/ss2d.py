@@ -176,7 +176,15 @@ class VSSBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, input: torch.Tensor):
-        return input + self.drop_path(self.self_attention(apply_norm(self.ln_1, input)))
+        y = self.self_attention(apply_norm(self.ln_1, input))
+        dp = self.drop_path
+        if type(dp) is DropPath and dp.training and dp.drop_prob > 0.0:
+            # residual + stochastic depth in one pass (same Bernoulli draw as DropPath.forward; y*(mask/keep) instead
+            # of (y*mask)/keep): input + y * mask / keep
+            keep = 1.0 - dp.drop_prob
+            mask = y.new_empty((y.shape[0],) + (1,) * (y.dim() - 1)).bernoulli_(keep)
+            return torch.addcmul(input, y, (mask / keep).to(input.dtype))
+        return input + dp(y)
 
 
 def _burn_out_proj_rng(module: nn.Module):
