@@ -181,11 +181,31 @@ def vssm_case(ref):
     print("vssm_tiny params", int(summary["n_params"]))
 
 
+def config0_case(ref):
+    """BASELINE.json configs[0]: the reference's own CPU-runnable case -- VSSM tiny (depths 2-2-2-2, dims 96..768,
+    seed 1337 as train_fully_supervised_2D_VIM.py:243-246), eval mode, one synthetic 1x1x224x224 slice repeated to
+    3 channels (vision_mamba.py:43-44), 4 classes, sequential selective_scan_ref path.  The model is NOT stored: the
+    same seed reproduces its initialisation bit for bit (vssm_tiny_init_summary.npz pins that)."""
+    ref.selective_scan_fn = selective_scan_ref
+    torch.manual_seed(1337)
+    m = ref.VSSM(patch_size=4, in_chans=3, num_classes=4, depths=[2, 2, 2, 2], drop_path_rate=0.2).eval()
+    x = torch.rand(1, 1, 224, 224, generator=torch.Generator().manual_seed(224))
+    with torch.no_grad():
+        y = m(x.repeat(1, 3, 1, 1))
+    np.savez_compressed(os.path.join(HERE, "config0_vssm_tiny_224.npz"), x=np_(x), logits=np_(y))
+    print("config0", y.shape, float(y.abs().mean()))
+
+
 if __name__ == "__main__":
+    import sys
     torch.set_num_threads(8)
     ref = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == "config0":     # add this fixture without rewriting the others
+        config0_case(ref)
+        sys.exit(0)
     index_tables(ref)
     ss2d_case(ref, "ss2d_2x8x5x7_s0.npz", 2, 8, 5, 7, seed=0, with_scan_args=True)
     ss2d_case(ref, "ss2d_1x16x8x8_s1.npz", 1, 16, 8, 8, seed=1, with_scan_args=True)
     ss2d_case(ref, "ss2d_2x96x14x14_s0.npz", 2, 96, 14, 14, seed=0, with_scan_args=False)
     vssm_case(ref)
+    config0_case(ref)

@@ -115,6 +115,20 @@ def test_vssm_small_logits_match_reference_golden():
     assert rel_max(y.cpu(), g["logits"]) < 5e-5 and rel_l2(y.cpu(), g["logits"]) < 2e-5
 
 
+def test_config0_vssm_tiny_224_logits_match_reference_golden():
+    """BASELINE.json configs[0]: MambaUNet (VSSM tiny) forward on one 1x1x224x224 slice, 4 classes, against the
+    logits the reference itself produced on CPU with its selective_scan_ref path (tests/golden/make_golden.py).
+    The weights are not in the fixture: seed 1337 reproduces the reference's initialisation bit for bit."""
+    from mamba_unet_amd import MambaUnet
+    g = np.load(os.path.join(GOLDEN, "config0_vssm_tiny_224.npz"))
+    torch.manual_seed(1337)
+    net = MambaUnet(img_size=224, num_classes=4).cuda().eval()
+    with torch.no_grad():
+        y = net(torch.from_numpy(g["x"]).cuda())          # 1 channel in: MambaUnet repeats it to 3 (vision_mamba.py:43-44)
+    assert y.shape == (1, 4, 224, 224)
+    assert rel_l2(y.cpu(), g["logits"]) < 2e-5 and rel_max(y.cpu(), g["logits"]) < 1e-4
+
+
 def test_mambaunet_train_step_runs():
     """One fully-supervised step (train_fully_supervised_2D_VIM.py:147-160) at a small size: finite loss,
     every parameter receives a gradient."""
