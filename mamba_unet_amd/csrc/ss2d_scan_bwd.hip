@@ -59,13 +59,16 @@ __device__ __forceinline__ void row_scan_rev_pair(float &rx, float &ry, float &a
                  "s_nop 1\n\t"
                  : "+v"(rx), "+v"(ry), "+v"(ax), "+v"(ay));
 }
-// sum over the 16 lanes of a row; the total lands in lane 15 of the row
-__device__ __forceinline__ float row_sum_to_lane15(float v) {
-    v += dpp_mov<DPP_ROW_SHR(1), 0xf, true>(0.0f, v);
-    v += dpp_mov<DPP_ROW_SHR(2), 0xf, true>(0.0f, v);
-    v += dpp_mov<DPP_ROW_SHR(4), 0xf, true>(0.0f, v);
-    v += dpp_mov<DPP_ROW_SHR(8), 0xf, true>(0.0f, v);
-    return v;
+// sum over the 16 lanes of a row; the total lands in lane 15 of the row.  Two values at once so that the DPP
+// read-after-write hazard of one chain is covered by the other; the shifted operand reads 0 outside the row
+// (bound_ctrl), and the add is fused into the DPP instruction (the compiler emits v_mov_dpp + v_add instead).
+__device__ __forceinline__ void row_sum2_to_lane15(float &x, float &y) {
+#define SS2D_ASTEP(n)                                                                              \
+    "v_add_f32_dpp %0, %0, %0 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %1, %1, %1 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "s_nop 0\n\t"
+    asm volatile("s_nop 1\n\t" SS2D_ASTEP(1) SS2D_ASTEP(2) SS2D_ASTEP(4) SS2D_ASTEP(8) : "+v"(x), "+v"(y));
+#undef SS2D_ASTEP
 }
 
 // Sum four per-lane values over the 4 DPP rows of the wave: on return row r of the result holds the
@@ -307,7 +310,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
                 const float cy = dpp_mov<DPP_ROW_ROR(15), 0xf, false>(0.0f, rr.y);
                 if (seg == 15) rc[(quad * NP + np) * 4 + row] = f2{cx, cy};
                 // dA (log2 units were only used for ddt): reduce over the row, accumulate over chunks in LDS
-                const float sx = row_sum_to_lane15(dAp.x), sy = row_sum_to_lane15(dAp.y);
+                float sx = dAp.x, sy = dAp.y;
+                row_sum2_to_lane15(sx, sy);
                 if (seg == 15) {
                     dAs[(quad * 4 + row) * 16 + 2 * np] += sx;
                     dAs[(quad * 4 + row) * 16 + 2 * np + 1] += sy;
@@ -328,7 +332,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
             }
             store8<VEC4>(static_cast<IO *>(p.du) + rowoff, p0, L, row_ok, duo);
             store8<VEC4>(static_cast<IO *>(p.ddelta) + rowoff, p0, L, row_ok, ddo);
-            const float sD = row_sum_to_lane15(dD_part), sb = row_sum_to_lane15(db_part);
+            float sD = dD_part, sb = db_part;
+            row_sum2_to_lane15(sD, sb);
             if (seg == 15) {
                 dXs[(quad * 4 + row) * 2] += sD;
                 dXs[(quad * 4 + row) * 2 + 1] += sb;
