@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--batch", type=int, default=24, help="slices per GPU")
     ap.add_argument("--dtype", choices=["fp32", "bf16", "bf16-fp32scan"], default="fp32",
                     help="bf16: autocast + bf16 kernel I/O; bf16-fp32scan: autocast with the reference's fp32 casts around the scan")
+    ap.add_argument("--literal-directions", action="store_true",
+                    help="A/B: run cross_scan / scan / cross_merge literally (4 materialised directions) instead of the fused-direction path")
     ap.add_argument("--graph", action="store_true", help="train mode, 1 GPU: capture the whole step in a HIP graph")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -60,6 +62,7 @@ def main():
     bf16 = args.dtype != "fp32"
     from mamba_unet_amd import SS2D
     SS2D.bf16_scan_io = args.dtype == "bf16"
+    SS2D.fused_directions = not args.literal_directions
     torch.manual_seed(1337)                       # train_fully_supervised_2D_VIM.py:243-246
     nets = [MambaUnet(img_size=args.size, num_classes=args.classes).to(dev) for _ in range(2 if args.mode == "semi" else 1)]
     n_params = sum(p.numel() for p in nets[0].parameters())

@@ -62,6 +62,27 @@ int ss2d_selective_scan_bwd(int dtype, const void *u, const void *delta, const f
                             float *dC, float *dD, void *dz, float *ddelta_bias, int batch, int dim, int L,
                             int dstate, int ngroups, int delta_softplus, void *stream);
 
+/* Direction-aware variants of the two calls above: the scan reads and writes the UN-permuted tensors in place.
+ *   rev_mask : bit g set = group g walks its rows backwards (scan position l <-> memory index L-1-l) for u, delta,
+ *              B, C, z, out and, in _bwd, dout, du, ddelta, dB, dC, dz.  This is how the two reversed directions of
+ *              CrossScan (mamba_sys.py:404, the torch.flip half of xs) and the un-flip of :446 run without any
+ *              flipped copy in HBM.  Checkpoints stay in scan order.
+ *   u_groups : u (and, in _bwd, dout) hold only u_groups groups per batch: (batch, u_groups * dim/ngroups, L);
+ *              scan group g uses group g / (ngroups / u_groups).  With the four SS2D directions ordered
+ *              (row-major, row-major reversed, column-major, column-major reversed), u_groups = 2 lets a direction
+ *              and its reversal share one copy of the input.  du is still written per scan group (batch, dim, L).
+ * ss2d_selective_scan_fwd/_bwd are these with u_groups = ngroups, rev_mask = 0.  ngroups <= 32 when rev_mask != 0. */
+int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                const void *C, const float *D, const void *z, const float *delta_bias, void *out,
+                                float *last_state, float *ckpt, int batch, int dim, int L, int dstate, int ngroups,
+                                int delta_softplus, int u_groups, unsigned rev_mask, void *stream);
+int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                const void *C, const float *D, const void *z, const float *delta_bias,
+                                const void *dout, const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
+                                float *dC, float *dD, void *dz, float *ddelta_bias, int batch, int dim, int L,
+                                int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask,
+                                void *stream);
+
 /* CrossScan (mamba_sys.py:403-404): x (B, D, H, W) -> xs (B, 4, D, H*W); _bwd is its adjoint
  * (sums the four directions back into dx). */
 int ss2d_cross_scan_fwd(int dtype, const void *x, void *xs, int B, int D, int H, int W, void *stream);
@@ -73,6 +94,23 @@ int ss2d_cross_merge_fwd(int dtype, const void *ys, void *y, int B, int D, int H
                          void *stream);
 int ss2d_cross_merge_bwd(int dtype, const void *dy, void *dys, int B, int D, int H, int W, int channel_last,
                          void *stream);
+
+/* The same two kernels with a selectable layout of the direction axis, for use with ss2d_selective_scan_dir_*:
+ *   SS2D_DIRS_REFERENCE     (b, 4, D, L): slots row-major, column-major, row-major reversed, column-major reversed
+ *                           (what mamba_sys.py:403-404 builds and :445-448 consumes);
+ *   SS2D_DIRS_MIRROR_FREE_4 (b, 4, D, L): slots row-major, row-major, column-major, column-major, nothing stored
+ *                           reversed (the scan's rev_mask does the reversal in place); slot pairs in scan-group order;
+ *   SS2D_DIRS_MIRROR_FREE_2 (b, 2, D, L): slots row-major, column-major (one copy per orientation, shared by a
+ *                           direction and its reversal through u_groups = 2).
+ * ss2d_dirs_scatter: x (B,D,H,W) or channel-last (B,H,W,D) -> every slot of xs;  ss2d_dirs_gather: y = sum over the
+ * slots of ys (same summation order as the reference: row-major pair first), y (B,D,H*W) or channel-last. */
+#define SS2D_DIRS_REFERENCE 0
+#define SS2D_DIRS_MIRROR_FREE_4 1
+#define SS2D_DIRS_MIRROR_FREE_2 2
+int ss2d_dirs_scatter(int dtype, int layout, const void *x, void *xs, int B, int D, int H, int W, int x_channel_last,
+                      void *stream);
+int ss2d_dirs_gather(int dtype, int layout, const void *ys, void *y, int B, int D, int H, int W, int y_channel_last,
+                     void *stream);
 
 /* Depthwise 3x3 conv (pad 1, bias) + SiLU (mamba_sys.py:299-308, :558-559).
  *   x: channel_last_in ? (B, H, W, ldx) with the D channels first (ldx >= D lets it read the x half of

@@ -91,5 +91,58 @@ __device__ __forceinline__ void store8(IO *__restrict__ row, int p0, int L, bool
     }
 }
 
+// ---- mirrored variants: `rev` (wave-uniform) means scan position l lives at memory index L-1-l, which is how a
+// reversed scan direction reads and writes the un-reversed tensors in place (no flipped copy in HBM).
+template <bool VEC4, typename IO>
+__device__ __forceinline__ void load8m(const IO *__restrict__ row, int p0, int L, bool ok, bool rev, float (&v)[8]) {
+    if (!rev) { load8<VEC4>(row, p0, L, ok, v); return; }
+    if (VEC4) {  // L % 4 == 0 and p0 % 4 == 0: each group of 4 is entirely inside or entirely outside
+        f4 a = f4{0, 0, 0, 0}, b = f4{0, 0, 0, 0};
+        if (ok && p0 < L) a = ld4(row + (L - 4 - p0));
+        if (ok && p0 + 4 < L) b = ld4(row + (L - 8 - p0));
+        v[0] = a.w; v[1] = a.z; v[2] = a.y; v[3] = a.x; v[4] = b.w; v[5] = b.z; v[6] = b.y; v[7] = b.x;
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = (ok && p0 + t < L) ? ld1(row + (L - 1 - p0 - t)) : 0.0f;
+    }
+}
+template <bool VEC4, typename IO>
+__device__ __forceinline__ void store8m(IO *__restrict__ row, int p0, int L, bool ok, bool rev, const float (&v)[8]) {
+    if (!rev) { store8<VEC4>(row, p0, L, ok, v); return; }
+    if (VEC4) {
+        if (ok && p0 < L) st4(row + (L - 4 - p0), f4{v[3], v[2], v[1], v[0]});
+        if (ok && p0 + 4 < L) st4(row + (L - 8 - p0), f4{v[7], v[6], v[5], v[4]});
+    } else {
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (ok && p0 + t < L) st1(row + (L - 1 - p0 - t), v[t]);
+    }
+}
+// compile-time switch: DIRS = false is exactly load8 / store8
+template <bool VEC4, bool DIRS, typename IO>
+__device__ __forceinline__ void load8d(const IO *__restrict__ row, int p0, int L, bool ok, bool rev, float (&v)[8]) {
+    if (DIRS) load8m<VEC4>(row, p0, L, ok, rev, v); else load8<VEC4>(row, p0, L, ok, v);
+}
+template <bool VEC4, bool DIRS, typename IO>
+__device__ __forceinline__ void store8d(IO *__restrict__ row, int p0, int L, bool ok, bool rev, const float (&v)[8]) {
+    if (DIRS) store8m<VEC4>(row, p0, L, ok, rev, v); else store8<VEC4>(row, p0, L, ok, v);
+}
+// 4 consecutive scan positions pos..pos+3 of one row (zero past L)
+template <bool VEC4, typename IO>
+__device__ __forceinline__ f4 load4m(const IO *__restrict__ row, int pos, int L, bool rev) {
+    f4 r = f4{0, 0, 0, 0};
+    if (VEC4) {
+        if (pos < L) {
+            if (!rev) r = ld4(row + pos);
+            else { const f4 t = ld4(row + (L - 4 - pos)); r = f4{t.w, t.z, t.y, t.x}; }
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (pos + e < L) r[e] = ld1(row + (rev ? L - 1 - pos - e : pos + e));
+    }
+    return r;
+}
+
 // thread-local error string shared by the C-ABI entry points
 void ss2d_set_error(const char *fmt, ...);

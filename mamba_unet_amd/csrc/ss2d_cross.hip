@@ -20,6 +20,10 @@ struct CrossParams {
     const void *in;    // scan: x ; merge: ys   (IO type: fp32 or bf16)
     void *out;         // scan: xs; merge: y
     int B, D, H, W, tiles_h, tiles_w, tiles_d;
+    // slot layout of the direction axis: row-major pair (slot 0, slot rmB), column-major pair (cmA, cmB); revB = the
+    // second slot of each pair is stored reversed (the reference's layout: rmB 2, cmA 1, cmB 3, revB 1).  The
+    // mirror-free layouts used with ss2d_selective_scan_dir_*: 4 slots (0,1 | 2,3), revB 0, or 2 slots (0 | 1).
+    int nslots, rmB, cmA, cmB, revB;
 };
 
 __device__ __forceinline__ void tile_coords(const CrossParams &p, int &b, int &d0, int &h0, int &w0) {
@@ -62,10 +66,9 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const float v = s[d * SD + h * SW + w];
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            IO *o0 = out + (((size_t)b * 4 + 0) * D + d0 + d) * L;
-            IO *o2 = out + (((size_t)b * 4 + 2) * D + d0 + d) * L;
+            IO *o0 = out + (((size_t)b * p.nslots + 0) * D + d0 + d) * L;
             st1(o0 + pp, v);
-            st1(o2 + (L - 1 - pp), v);
+            if (p.nslots == 4) st1(out + (((size_t)b * 4 + p.rmB) * D + d0 + d) * L + (p.revB ? L - 1 - pp : pp), v);
         }
     }
     // column-major directions 1 and 3: h on the fast lanes
@@ -74,10 +77,9 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const float v = s[d * SD + h * SW + w];
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            IO *o1 = out + (((size_t)b * 4 + 1) * D + d0 + d) * L;
-            IO *o3 = out + (((size_t)b * 4 + 3) * D + d0 + d) * L;
+            IO *o1 = out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L;
             st1(o1 + q, v);
-            st1(o3 + (L - 1 - q), v);
+            if (p.nslots == 4) st1(out + (((size_t)b * 4 + p.cmB) * D + d0 + d) * L + (p.revB ? L - 1 - q : q), v);
         }
     }
 }
@@ -97,9 +99,9 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
         float v = 0.0f;
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            const IO *i0 = in + (((size_t)b * 4 + 0) * D + d0 + d) * L;
-            const IO *i2 = in + (((size_t)b * 4 + 2) * D + d0 + d) * L;
-            v = ld1(i0 + pp) + ld1(i2 + (L - 1 - pp));
+            const IO *i0 = in + (((size_t)b * p.nslots + 0) * D + d0 + d) * L;
+            v = ld1(i0 + pp);
+            if (p.nslots == 4) v += ld1(in + (((size_t)b * 4 + p.rmB) * D + d0 + d) * L + (p.revB ? L - 1 - pp : pp));
         }
         s[d * SD + h * SW + w] = v;
     }
@@ -108,10 +110,11 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
         const int h = i & (TH - 1), w = (i >> 4) & (TW - 1), d = i >> 8;
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            const IO *i1 = in + (((size_t)b * 4 + 1) * D + d0 + d) * L;
-            const IO *i3 = in + (((size_t)b * 4 + 3) * D + d0 + d) * L;
+            const IO *i1 = in + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L;
             // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
-            s[d * SD + h * SW + w] = (s[d * SD + h * SW + w] + ld1(i1 + q)) + ld1(i3 + (L - 1 - q));
+            float acc = s[d * SD + h * SW + w] + ld1(i1 + q);
+            if (p.nslots == 4) acc += ld1(in + (((size_t)b * 4 + p.cmB) * D + d0 + d) * L + (p.revB ? L - 1 - q : q));
+            s[d * SD + h * SW + w] = acc;
         }
     }
     __syncthreads();
@@ -170,8 +173,11 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = s[d * SD + h * SW + w + e];
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            st4(out + (((size_t)b * 4 + 0) * D + d0 + d) * L + pp, v);
-            st4(out + (((size_t)b * 4 + 2) * D + d0 + d) * L + (L - 4 - pp), rev4(v));
+            st4(out + (((size_t)b * p.nslots + 0) * D + d0 + d) * L + pp, v);
+            if (p.nslots == 4) {
+                IO *o2 = out + (((size_t)b * 4 + p.rmB) * D + d0 + d) * L;
+                if (p.revB) st4(o2 + (L - 4 - pp), rev4(v)); else st4(o2 + pp, v);
+            }
         }
     }
     for (int i = tid; i < TD * TH * TW / 4; i += 256) {   // directions 1 and 3: runs along h
@@ -181,8 +187,11 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = s[d * SD + (h + e) * SW + w];
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            st4(out + (((size_t)b * 4 + 1) * D + d0 + d) * L + q, v);
-            st4(out + (((size_t)b * 4 + 3) * D + d0 + d) * L + (L - 4 - q), rev4(v));
+            st4(out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L + q, v);
+            if (p.nslots == 4) {
+                IO *o3 = out + (((size_t)b * 4 + p.cmB) * D + d0 + d) * L;
+                if (p.revB) st4(o3 + (L - 4 - q), rev4(v)); else st4(o3 + q, v);
+            }
         }
     }
 }
@@ -201,8 +210,11 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
         f4 v = f4{0, 0, 0, 0};
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            v = ld4(in + (((size_t)b * 4 + 0) * D + d0 + d) * L + pp) +
-                rev4(ld4(in + (((size_t)b * 4 + 2) * D + d0 + d) * L + (L - 4 - pp)));
+            v = ld4(in + (((size_t)b * p.nslots + 0) * D + d0 + d) * L + pp);
+            if (p.nslots == 4) {
+                const IO *i2 = in + (((size_t)b * 4 + p.rmB) * D + d0 + d) * L;
+                v += p.revB ? rev4(ld4(i2 + (L - 4 - pp))) : ld4(i2 + pp);
+            }
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[d * SD + h * SW + w + e] = v[e];
@@ -212,11 +224,18 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
         const int h = (i & 3) * 4, w = (i >> 2) & (TW - 1), d = i >> 6;
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            const f4 v1 = ld4(in + (((size_t)b * 4 + 1) * D + d0 + d) * L + q);
-            const f4 v3 = rev4(ld4(in + (((size_t)b * 4 + 3) * D + d0 + d) * L + (L - 4 - q)));
+            const f4 v1 = ld4(in + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L + q);
+            f4 v3 = f4{0, 0, 0, 0};
+            if (p.nslots == 4) {
+                const IO *i3 = in + (((size_t)b * 4 + p.cmB) * D + d0 + d) * L;
+                v3 = p.revB ? rev4(ld4(i3 + (L - 4 - q))) : ld4(i3 + q);
+            }
             // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[d * SD + (h + e) * SW + w] = (s[d * SD + (h + e) * SW + w] + v1[e]) + v3[e];
+            for (int e = 0; e < 4; ++e) {
+                const float acc = s[d * SD + (h + e) * SW + w] + v1[e];
+                s[d * SD + (h + e) * SW + w] = p.nslots == 4 ? acc + v3[e] : acc;
+            }
         }
     }
     __syncthreads();
@@ -243,12 +262,16 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
     }
 }
 
-int run(bool merge, bool cl, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name) {
+int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("%s: unknown dtype %d", name, dtype); return -1; }
     if (!in || !out) { ss2d_set_error("%s: null pointer", name); return -2; }
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
     CrossParams p;
     p.in = in; p.out = out; p.B = B; p.D = D; p.H = H; p.W = W;
+    if (layout == SS2D_DIRS_REFERENCE) { p.nslots = 4; p.rmB = 2; p.cmA = 1; p.cmB = 3; p.revB = 1; }
+    else if (layout == SS2D_DIRS_MIRROR_FREE_4) { p.nslots = 4; p.rmB = 1; p.cmA = 2; p.cmB = 3; p.revB = 0; }
+    else if (layout == SS2D_DIRS_MIRROR_FREE_2) { p.nslots = 2; p.rmB = 0; p.cmA = 1; p.cmB = 1; p.revB = 0; }
+    else { ss2d_set_error("%s: unknown direction layout %d", name, layout); return -7; }
     p.tiles_h = (H + TH - 1) / TH; p.tiles_w = (W + TW - 1) / TW; p.tiles_d = (D + TD - 1) / TD;
     const long long n = (long long)B * p.tiles_d * p.tiles_h * p.tiles_w;
     if (n > 0x7fffffffLL) { ss2d_set_error("%s: grid too large", name); return -6; }
@@ -280,14 +303,21 @@ int run(bool merge, bool cl, int dtype, const void *in, void *out, int B, int D,
 }  // namespace
 
 extern "C" int ss2d_cross_scan_fwd(int dtype, const void *x, void *xs, int B, int D, int H, int W, void *stream) {
-    return run(false, false, dtype, x, xs, B, D, H, W, stream, "cross_scan_fwd");
+    return run(false, false, SS2D_DIRS_REFERENCE, dtype, x, xs, B, D, H, W, stream, "cross_scan_fwd");
 }
 extern "C" int ss2d_cross_scan_bwd(int dtype, const void *dxs, void *dx, int B, int D, int H, int W, void *stream) {
-    return run(true, false, dtype, dxs, dx, B, D, H, W, stream, "cross_scan_bwd");
+    return run(true, false, SS2D_DIRS_REFERENCE, dtype, dxs, dx, B, D, H, W, stream, "cross_scan_bwd");
 }
 extern "C" int ss2d_cross_merge_fwd(int dtype, const void *ys, void *y, int B, int D, int H, int W, int channel_last, void *stream) {
-    return run(true, channel_last != 0, dtype, ys, y, B, D, H, W, stream, "cross_merge_fwd");
+    return run(true, channel_last != 0, SS2D_DIRS_REFERENCE, dtype, ys, y, B, D, H, W, stream, "cross_merge_fwd");
 }
 extern "C" int ss2d_cross_merge_bwd(int dtype, const void *dy, void *dys, int B, int D, int H, int W, int channel_last, void *stream) {
-    return run(false, channel_last != 0, dtype, dy, dys, B, D, H, W, stream, "cross_merge_bwd");
+    return run(false, channel_last != 0, SS2D_DIRS_REFERENCE, dtype, dy, dys, B, D, H, W, stream, "cross_merge_bwd");
+}
+// generic forms: `layout` picks the slot layout of the direction axis (include/ss2d.h)
+extern "C" int ss2d_dirs_scatter(int dtype, int layout, const void *x, void *xs, int B, int D, int H, int W, int x_channel_last, void *stream) {
+    return run(false, x_channel_last != 0, layout, dtype, x, xs, B, D, H, W, stream, "dirs_scatter");
+}
+extern "C" int ss2d_dirs_gather(int dtype, int layout, const void *ys, void *y, int B, int D, int H, int W, int y_channel_last, void *stream) {
+    return run(true, y_channel_last != 0, layout, dtype, ys, y, B, D, H, W, stream, "dirs_gather");
 }

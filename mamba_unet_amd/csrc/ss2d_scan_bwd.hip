@@ -30,6 +30,8 @@ struct ScanBwdParams {
     void *du, *ddelta, *dz;                      // IO type
     float *dA, *dB, *dC, *dD, *dbias;            // fp32 accumulators (atomics)
     int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg, rounds, cb;
+    int Gu;              // u and dout have Gu groups per batch; scan group g uses group g / (G / Gu)
+    unsigned rev_mask;   // bit g: group g runs over its rows in reverse memory order
 };
 
 #define SS2D_FSTEP(n)                                                                  \
@@ -90,7 +92,8 @@ __device__ __forceinline__ void rows_reduce4x2(float &x0, float x1, float x2, fl
                  : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
 }
 
-template <int NW, bool HAS_Z, bool VEC4, typename IO>
+// DIRS: direction-aware build (rev_mask / u_groups honoured); false compiles the mirrored paths away
+template <int NW, bool HAS_Z, bool VEC4, typename IO, bool DIRS>
 __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     f4 *tile = reinterpret_cast<f4 *>(smem);                                   // [2][NP*4*16] f4 = 16 KB
@@ -105,6 +108,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
     blk /= p.wgs_per_group;
     const int g = blk % p.G, b = blk / p.G;
     const int L = p.L, N = p.N;
+    const bool rev = DIRS && ((p.rev_mask >> g) & 1u);
+    const int ug = DIRS ? g / (p.G / p.Gu) : g;
     const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * N * (size_t)L;
     const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * N * (size_t)L;
     float *__restrict__ dBg = p.dB + (size_t)(b * p.G + g) * N * (size_t)L;
@@ -125,7 +130,10 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
             for (int m = 0; m < 2; ++m) {
                 const IO *__restrict__ M = m ? Cg : Bg;
                 f4 lo = f4{0, 0, 0, 0}, hi = f4{0, 0, 0, 0};
-                if (VEC4) {
+                if (DIRS) {
+                    if (n0 < N) lo = load4m<VEC4>(M + (size_t)n0 * L, pos, L, rev);
+                    if (n1 < N) hi = load4m<VEC4>(M + (size_t)n1 * L, pos, L, rev);
+                } else if (VEC4) {
                     if (pos < L) {
                         if (n0 < N) lo = ld4(M + (size_t)n0 * L + pos);
                         if (n1 < N) hi = ld4(M + (size_t)n1 * L + pos);
@@ -154,9 +162,10 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
             const size_t rowoff = ((size_t)b * p.dim + c) * (size_t)L;
             const int p0 = base + seg * T;
             float uv[T], dt[T], sg[T], dyv[T], du_[T];
-            load8<VEC4>(static_cast<const IO *>(p.u) + rowoff, p0, L, row_ok, uv);
-            load8<VEC4>(static_cast<const IO *>(p.delta) + rowoff, p0, L, row_ok, dt);
-            load8<VEC4>(static_cast<const IO *>(p.dout) + rowoff, p0, L, row_ok, dyv);
+            const size_t urowoff = DIRS ? (((size_t)b * p.Gu + ug) * p.dpg + (row_ok ? c_in_g : 0)) * (size_t)L : rowoff;
+            load8d<VEC4, DIRS>(static_cast<const IO *>(p.u) + urowoff, p0, L, row_ok, rev, uv);
+            load8d<VEC4, DIRS>(static_cast<const IO *>(p.delta) + rowoff, p0, L, row_ok, rev, dt);
+            load8d<VEC4, DIRS>(static_cast<const IO *>(p.dout) + urowoff, p0, L, row_ok, rev, dyv);
             const float bias = p.bias ? p.bias[c] : 0.0f;
             const float Dc = p.D ? p.D[c] : 0.0f;
             float S = 0.0f;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
             float zs[T], zv[T];  // silu(z) and z when gated
             if (HAS_Z) {
                 // gate: out = y * silu(z) with y = sum_n C h + D u, so y has to be rebuilt first
-                load8<VEC4>(static_cast<const IO *>(p.z) + rowoff, p0, L, row_ok, zv);
+                load8d<VEC4, DIRS>(static_cast<const IO *>(p.z) + rowoff, p0, L, row_ok, rev, zv);
                 f2 y2[T];
 #pragma unroll
                 for (int t = 0; t < T; ++t) y2[t] = f2{Dc * uv[t], 0.0f};
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
                     dzv[t] = dyv[t] * y * (s_ * (1.0f + zv[t] * (1.0f - s_)));
                     dyv[t] *= zs[t];
                 }
-                store8<VEC4>(static_cast<IO *>(p.dz) + rowoff, p0, L, row_ok, dzv);
+                store8d<VEC4, DIRS>(static_cast<IO *>(p.dz) + rowoff, p0, L, row_ok, rev, dzv);
             }
 
             f2 ddt2[T], ddu2[T];
@@ -330,8 +339,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
                 dD_part += dyv[t] * uv[t];
                 db_part += ddo[t];
             }
-            store8<VEC4>(static_cast<IO *>(p.du) + rowoff, p0, L, row_ok, duo);
-            store8<VEC4>(static_cast<IO *>(p.ddelta) + rowoff, p0, L, row_ok, ddo);
+            store8d<VEC4, DIRS>(static_cast<IO *>(p.du) + rowoff, p0, L, row_ok, rev, duo);
+            store8d<VEC4, DIRS>(static_cast<IO *>(p.ddelta) + rowoff, p0, L, row_ok, rev, ddo);
             float sD = dD_part, sb = db_part;
             row_sum2_to_lane15(sD, sb);
             if (seg == 15) {
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += acc[w * ACC_WAVE_FLOATS + off];
 #if !defined(SS2D_ABLATE_FLUSH)
-            if (n < N && base + pos < L) atomicAdd((mat ? dCg : dBg) + (size_t)n * L + base + pos, v);
+            if (n < N && base + pos < L) atomicAdd((mat ? dCg : dBg) + (size_t)n * L + (rev ? L - 1 - base - pos : base + pos), v);
 #else
             asm volatile("" ::"v"(v));
 #endif
@@ -375,25 +384,25 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
     }
 }
 
-template <int NW, bool HAS_Z, bool VEC4, typename IO>
+template <int NW, bool HAS_Z, bool VEC4, typename IO, bool DIRS>
 int launch_one(const ScanBwdParams &p, size_t lds, hipStream_t s) {
-    auto kern = scan_bwd_kernel<NW, HAS_Z, VEC4, IO>;
+    auto kern = scan_bwd_kernel<NW, HAS_Z, VEC4, IO, DIRS>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(NW * 64), lds, s, p);
     return (int)hipGetLastError();
 }
-template <int NW, typename IO>
+template <int NW, typename IO, bool DIRS>
 int launch_bwd(const ScanBwdParams &p, bool has_z, bool vec4, size_t lds, hipStream_t s) {
-    if (has_z) return vec4 ? launch_one<NW, true, true, IO>(p, lds, s) : launch_one<NW, true, false, IO>(p, lds, s);
-    return vec4 ? launch_one<NW, false, true, IO>(p, lds, s) : launch_one<NW, false, false, IO>(p, lds, s);
+    if (has_z) return vec4 ? launch_one<NW, true, true, IO, DIRS>(p, lds, s) : launch_one<NW, true, false, IO, DIRS>(p, lds, s);
+    return vec4 ? launch_one<NW, false, true, IO, DIRS>(p, lds, s) : launch_one<NW, false, false, IO, DIRS>(p, lds, s);
 }
-template <typename IO>
+template <typename IO, bool DIRS>
 int launch_bwd_nw(int nw, const ScanBwdParams &p, bool has_z, bool vec4, size_t lds, hipStream_t s) {
-    return nw == 8 ? launch_bwd<8, IO>(p, has_z, vec4, lds, s)
-         : nw == 4 ? launch_bwd<4, IO>(p, has_z, vec4, lds, s)
-         : nw == 2 ? launch_bwd<2, IO>(p, has_z, vec4, lds, s)
-                   : launch_bwd<1, IO>(p, has_z, vec4, lds, s);
+    return nw == 8 ? launch_bwd<8, IO, DIRS>(p, has_z, vec4, lds, s)
+         : nw == 4 ? launch_bwd<4, IO, DIRS>(p, has_z, vec4, lds, s)
+         : nw == 2 ? launch_bwd<2, IO, DIRS>(p, has_z, vec4, lds, s)
+                   : launch_bwd<1, IO, DIRS>(p, has_z, vec4, lds, s);
 }
 
 }  // namespace
@@ -403,6 +412,16 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
                                        const void *dout, const float *ckpt, void *du, void *ddelta, float *dA,
                                        float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
                                        int dim, int L, int dstate, int ngroups, int delta_softplus, void *stream) {
+    return ss2d_selective_scan_dir_bwd(dtype, u, delta, A, B, C, D, z, delta_bias, dout, ckpt, du, ddelta, dA, dB, dC, dD,
+                                       dz, ddelta_bias, batch, dim, L, dstate, ngroups, delta_softplus, ngroups, 0u, stream);
+}
+
+extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                           const void *C, const float *D, const void *z, const float *delta_bias,
+                                           const void *dout, const float *ckpt, void *du, void *ddelta, float *dA,
+                                           float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
+                                           int dim, int L, int dstate, int ngroups, int delta_softplus, int u_groups,
+                                           unsigned rev_mask, void *stream) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_bwd: unknown dtype %d", dtype); return -1; }
     if (!u || !delta || !A || !B || !C || !dout || !ckpt || !du || !ddelta || !dA || !dB || !dC) {
         ss2d_set_error("selective_scan_bwd: null required pointer"); return -2; }
@@ -410,7 +429,10 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
     if (batch <= 0 || dim <= 0 || L <= 0 || dstate <= 0 || ngroups <= 0) { ss2d_set_error("selective_scan_bwd: non-positive size"); return -3; }
     if (dstate > SS2D_MAX_DSTATE) { ss2d_set_error("selective_scan_bwd: dstate %d > %d", dstate, SS2D_MAX_DSTATE); return -4; }
     if (dim % ngroups) { ss2d_set_error("selective_scan_bwd: dim %d not divisible by ngroups %d", dim, ngroups); return -5; }
+    if (u_groups <= 0 || ngroups % u_groups) { ss2d_set_error("selective_scan_bwd: u_groups %d must divide ngroups %d", u_groups, ngroups); return -5; }
+    if (ngroups > 32 && rev_mask) { ss2d_set_error("selective_scan_bwd: rev_mask needs ngroups <= 32"); return -5; }
     ScanBwdParams p;
+    p.Gu = u_groups; p.rev_mask = rev_mask;
     p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
     p.D = D; p.z = z; p.bias = delta_bias; p.dout = dout; p.ckpt = ckpt;
     p.du = du; p.ddelta = ddelta; p.dA = dA; p.dB = dB; p.dC = dC; p.dD = D ? dD : nullptr;
@@ -442,8 +464,10 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
     const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dout |
                                          (uintptr_t)du | (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
-    int rc = dtype == SS2D_DTYPE_BF16 ? launch_bwd_nw<bf16>(nw, p, z != nullptr, vec4, lds, s)
-                                      : launch_bwd_nw<float>(nw, p, z != nullptr, vec4, lds, s);
+    const bool dirs = rev_mask != 0 || u_groups != ngroups;
+    int rc = dtype == SS2D_DTYPE_BF16
+                 ? (dirs ? launch_bwd_nw<bf16, true>(nw, p, z != nullptr, vec4, lds, s) : launch_bwd_nw<bf16, false>(nw, p, z != nullptr, vec4, lds, s))
+                 : (dirs ? launch_bwd_nw<float, true>(nw, p, z != nullptr, vec4, lds, s) : launch_bwd_nw<float, false>(nw, p, z != nullptr, vec4, lds, s));
     if (rc) ss2d_set_error("selective_scan_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

@@ -30,6 +30,8 @@ struct ScanFwdParams {
     void *out;                            // IO type
     float *last, *ckpt;
     int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg;
+    int Gu;              // u has Gu groups per batch; scan group g reads u group g / (G / Gu)
+    unsigned rev_mask;   // bit g: group g runs over its rows in reverse memory order
 };
 
 // Inclusive scan of (a, h) over the 16 lanes of each DPP row, two independent states interleaved so
@@ -49,7 +51,8 @@ __device__ __forceinline__ void row_scan_pair(float &hx, float &hy, float &ax, f
 }
 
 // FULL: dstate == 16 known at compile time (the only value Mamba-UNet uses): no per-pair bounds checks
-template <int NW, bool HAS_Z, bool VEC4, bool FULL, typename IO>
+// DIRS: direction-aware build (rev_mask / u_groups honoured); false compiles the mirrored paths away
+template <int NW, bool HAS_Z, bool VEC4, bool FULL, typename IO, bool DIRS>
 __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p) {
     // [buffer][B|C][(pair*4 + quarter)*16 + seg] ; one f4 = (n,t),(n+1,t),(n,t+1),(n+1,t+1)
     __shared__ f4 tile[2][2][NP * 4 * 16];
@@ -65,7 +68,9 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     const int L = p.L, N = FULL ? 16 : p.N;
 
     const size_t rowoff = ((size_t)b * p.dim + c) * (size_t)L;
-    const IO *__restrict__ urow = static_cast<const IO *>(p.u) + rowoff;
+    const bool rev = DIRS && ((p.rev_mask >> g) & 1u);
+    const size_t urowoff = DIRS ? (((size_t)b * p.Gu + g / (p.G / p.Gu)) * p.dpg + (row_ok ? c_in_g : 0)) * (size_t)L : rowoff;
+    const IO *__restrict__ urow = static_cast<const IO *>(p.u) + urowoff;
     const IO *__restrict__ drow = static_cast<const IO *>(p.delta) + rowoff;
     const IO *__restrict__ zrow = HAS_Z ? static_cast<const IO *>(p.z) + rowoff : nullptr;
     IO *__restrict__ orow = static_cast<IO *>(p.out) + rowoff;
@@ -85,8 +90,8 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
 
     // software prefetch: the next chunk's u / delta are requested before the current chunk is computed
     float un[T], dn[T];
-    load8<VEC4>(urow, seg * T, L, row_ok, un);
-    load8<VEC4>(drow, seg * T, L, row_ok, dn);
+    load8d<VEC4, DIRS>(urow, seg * T, L, row_ok, rev, un);
+    load8d<VEC4, DIRS>(drow, seg * T, L, row_ok, rev, dn);
 
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int buf = chunk & 1;
@@ -100,7 +105,10 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
             for (int m = 0; m < 2; ++m) {
                 const IO *__restrict__ M = m ? Cg : Bg;
                 f4 lo = f4{0, 0, 0, 0}, hi = f4{0, 0, 0, 0};
-                if (VEC4) {
+                if (DIRS) {
+                    if (n0 < N) lo = load4m<VEC4>(M + (size_t)n0 * L, pos, L, rev);
+                    if (n1 < N) hi = load4m<VEC4>(M + (size_t)n1 * L, pos, L, rev);
+                } else if (VEC4) {
                     if (pos < L) {
                         if (n0 < N) lo = ld4(M + (size_t)n0 * L + pos);
                         if (n1 < N) hi = ld4(M + (size_t)n1 * L + pos);
@@ -125,8 +133,8 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
 #pragma unroll
         for (int t = 0; t < T; ++t) { uv[t] = un[t]; dt[t] = dn[t]; }
         if (chunk + 1 < p.nchunks) {
-            load8<VEC4>(urow, p0 + CHUNK, L, row_ok, un);
-            load8<VEC4>(drow, p0 + CHUNK, L, row_ok, dn);
+            load8d<VEC4, DIRS>(urow, p0 + CHUNK, L, row_ok, rev, un);
+            load8d<VEC4, DIRS>(drow, p0 + CHUNK, L, row_ok, rev, dn);
         }
         float S = 0.0f;
 #pragma unroll
@@ -204,11 +212,11 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
         for (int t = 0; t < T; ++t) yv[t] = y2[t].x + y2[t].y;
         if (HAS_Z) {
             float zv[T];
-            load8<VEC4>(zrow, p0, L, row_ok, zv);
+            load8d<VEC4, DIRS>(zrow, p0, L, row_ok, rev, zv);
 #pragma unroll
             for (int t = 0; t < T; ++t) yv[t] *= zv[t] * sigmoidf_fast(zv[t]);
         }
-        store8<VEC4>(orow, p0, L, row_ok, yv);
+        store8d<VEC4, DIRS>(orow, p0, L, row_ok, rev, yv);
     }
     if (p.last != nullptr && seg == 0 && row_ok) {
 #pragma unroll
@@ -219,25 +227,25 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     }
 }
 
-template <int NW, typename IO>
+template <int NW, typename IO, bool DIRS>
 int launch_fwd(const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
     dim3 grid(p.nwg), block(NW * 64);
     const bool full = p.N == 16;
     if (has_z) {
-        if (vec4) hipLaunchKernelGGL((scan_fwd_kernel<NW, true, true, false, IO>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scan_fwd_kernel<NW, true, false, false, IO>), grid, block, 0, s, p);
+        if (vec4) hipLaunchKernelGGL((scan_fwd_kernel<NW, true, true, false, IO, DIRS>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scan_fwd_kernel<NW, true, false, false, IO, DIRS>), grid, block, 0, s, p);
     } else if (vec4 && full) {
-        hipLaunchKernelGGL((scan_fwd_kernel<NW, false, true, true, IO>), grid, block, 0, s, p);  // the SS2D call pattern
+        hipLaunchKernelGGL((scan_fwd_kernel<NW, false, true, true, IO, DIRS>), grid, block, 0, s, p);  // the SS2D call pattern
     } else {
-        if (vec4) hipLaunchKernelGGL((scan_fwd_kernel<NW, false, true, false, IO>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scan_fwd_kernel<NW, false, false, false, IO>), grid, block, 0, s, p);
+        if (vec4) hipLaunchKernelGGL((scan_fwd_kernel<NW, false, true, false, IO, DIRS>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((scan_fwd_kernel<NW, false, false, false, IO, DIRS>), grid, block, 0, s, p);
     }
     return (int)hipGetLastError();
 }
-template <typename IO>
+template <typename IO, bool DIRS>
 int launch_fwd_nw(int nw, const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
-    return nw == 4 ? launch_fwd<4, IO>(p, has_z, vec4, s) : nw == 2 ? launch_fwd<2, IO>(p, has_z, vec4, s)
-                                                                     : launch_fwd<1, IO>(p, has_z, vec4, s);
+    return nw == 4 ? launch_fwd<4, IO, DIRS>(p, has_z, vec4, s) : nw == 2 ? launch_fwd<2, IO, DIRS>(p, has_z, vec4, s)
+                                                                           : launch_fwd<1, IO, DIRS>(p, has_z, vec4, s);
 }
 
 }  // namespace
@@ -252,12 +260,24 @@ extern "C" int ss2d_selective_scan_fwd(int dtype, const void *u, const void *del
                                        const void *C, const float *D, const void *z, const float *delta_bias,
                                        void *out, float *last_state, float *ckpt, int batch, int dim, int L,
                                        int dstate, int ngroups, int delta_softplus, void *stream) {
+    return ss2d_selective_scan_dir_fwd(dtype, u, delta, A, B, C, D, z, delta_bias, out, last_state, ckpt, batch, dim, L,
+                                       dstate, ngroups, delta_softplus, ngroups, 0u, stream);
+}
+
+extern "C" int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                           const void *C, const float *D, const void *z, const float *delta_bias,
+                                           void *out, float *last_state, float *ckpt, int batch, int dim, int L,
+                                           int dstate, int ngroups, int delta_softplus, int u_groups,
+                                           unsigned rev_mask, void *stream) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_fwd: unknown dtype %d", dtype); return -1; }
     if (!u || !delta || !A || !B || !C || !out) { ss2d_set_error("selective_scan_fwd: null required pointer"); return -2; }
     if (batch <= 0 || dim <= 0 || L <= 0 || dstate <= 0 || ngroups <= 0) { ss2d_set_error("selective_scan_fwd: non-positive size"); return -3; }
     if (dstate > SS2D_MAX_DSTATE) { ss2d_set_error("selective_scan_fwd: dstate %d > %d", dstate, SS2D_MAX_DSTATE); return -4; }
     if (dim % ngroups) { ss2d_set_error("selective_scan_fwd: dim %d not divisible by ngroups %d", dim, ngroups); return -5; }
+    if (u_groups <= 0 || ngroups % u_groups) { ss2d_set_error("selective_scan_fwd: u_groups %d must divide ngroups %d", u_groups, ngroups); return -5; }
+    if (ngroups > 32 && rev_mask) { ss2d_set_error("selective_scan_fwd: rev_mask needs ngroups <= 32"); return -5; }
     ScanFwdParams p;
+    p.Gu = u_groups; p.rev_mask = rev_mask;
     p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
     p.D = D; p.z = z; p.bias = delta_bias; p.out = out; p.last = last_state; p.ckpt = ckpt;
     p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
@@ -272,8 +292,10 @@ extern "C" int ss2d_selective_scan_fwd(int dtype, const void *u, const void *del
     const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)out |
                                          (uintptr_t)z) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
-    int rc = dtype == SS2D_DTYPE_BF16 ? launch_fwd_nw<bf16>(nw, p, z != nullptr, vec4, s)
-                                      : launch_fwd_nw<float>(nw, p, z != nullptr, vec4, s);
+    const bool dirs = rev_mask != 0 || u_groups != ngroups;
+    int rc = dtype == SS2D_DTYPE_BF16
+                 ? (dirs ? launch_fwd_nw<bf16, true>(nw, p, z != nullptr, vec4, s) : launch_fwd_nw<bf16, false>(nw, p, z != nullptr, vec4, s))
+                 : (dirs ? launch_fwd_nw<float, true>(nw, p, z != nullptr, vec4, s) : launch_fwd_nw<float, false>(nw, p, z != nullptr, vec4, s));
     if (rc) ss2d_set_error("selective_scan_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

@@ -126,3 +126,77 @@ def selective_scan_fn(u, delta, A, B, C, D=None, z=None, delta_bias=None, delta_
     """u, delta (b, d, l); A (d, n); B, C (b, n, l) or (b, g, n, l); D, delta_bias (d); z (b, d, l).
     Returns out (b, d, l) in u's dtype [, last_state (b, d, n) fp32]."""
     return SelectiveScanFn.apply(u, delta, A, B, C, D, z, delta_bias, delta_softplus, return_last_state)
+
+
+class ScanMergeFn(torch.autograd.Function):
+    """Direction-aware selective scan + CrossMerge in one autograd node (mamba_sys.py:436-449 without the flips):
+    the scan groups are ordered (row-major, row-major reversed, column-major, column-major reversed); reversed groups
+    walk the un-flipped tensors backwards in place (rev_mask), a direction and its reversal share one copy of u and,
+    in the backward, one copy of dout (u_groups = 2).  Returns the merged y (B, H, W, D)."""
+
+    REV_MASK, U_GROUPS = 0b1010, 2
+
+    @staticmethod
+    def forward(ctx, u2, delta, A, Bm, Cm, D, delta_bias, H, W):
+        if not u2.is_cuda:
+            raise RuntimeError("scan_merge_fn: GPU tensors required (no CPU path in mamba_unet_amd)")
+        batch, dim, L = delta.shape
+        G, N = Bm.shape[1], A.shape[1]
+        if G != 4 or L != H * W or u2.shape != (batch, dim // 2, L) or Bm.shape != (batch, 4, N, L) or Cm.shape != Bm.shape:
+            raise ValueError(f"scan_merge_fn: inconsistent shapes u {tuple(u2.shape)} delta {tuple(delta.shape)} B {tuple(Bm.shape)}")
+        io = torch.bfloat16 if u2.dtype == torch.bfloat16 else torch.float32
+        code = _BF16 if io == torch.bfloat16 else _F32
+        u_, delta_, B_, C_ = _prep(u2, "u", io), _prep(delta, "delta", io), _prep(Bm, "B", io), _prep(Cm, "C", io)
+        A_, D_, bias_ = _prep(A, "A"), _prep(D, "D"), _prep(delta_bias, "delta_bias")
+        needs_grad = any(t is not None and t.requires_grad for t in (u2, delta, A, Bm, Cm, D, delta_bias))
+        lib = _lib.load()
+        out = torch.empty((batch, dim, L), device=u_.device, dtype=io)
+        ckpt = torch.empty((batch, dim, lib.ss2d_scan_num_chunks(L), N), device=u_.device, dtype=torch.float32) if needs_grad else None
+        Dch = dim // 4
+        y = torch.empty((batch, H, W, Dch), device=u_.device, dtype=io)
+        with torch.cuda.device(u_.device):
+            rc = lib.ss2d_selective_scan_dir_fwd(code, _lib.ptr(u_), _lib.ptr(delta_), _lib.ptr(A_), _lib.ptr(B_), _lib.ptr(C_),
+                                                 _lib.ptr(D_), None, _lib.ptr(bias_), _lib.ptr(out), None, _lib.ptr(ckpt),
+                                                 batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, _stream())
+            _lib.check(rc, "ss2d_selective_scan_dir_fwd")
+            rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(out), _lib.ptr(y), batch, Dch, H, W, 1, _stream())
+            _lib.check(rc, "ss2d_dirs_gather")
+        ctx.save_for_backward(u_, delta_, A_, B_, C_, D_, bias_, ckpt)
+        ctx.meta = (code, H, W, u2.dtype, delta.dtype, A.dtype, Bm.dtype, Cm.dtype, None if D is None else D.dtype,
+                    None if delta_bias is None else delta_bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, delta, A, Bm, Cm, D, bias, ckpt = ctx.saved_tensors
+        code, H, W, *dts = ctx.meta
+        batch, dim, L = delta.shape
+        N, Dch = A.shape[1], dim // 4
+        lib = _lib.load()
+        g = dy.to(u.dtype).contiguous()
+        dys2 = torch.empty((batch, 2, Dch, L), device=g.device, dtype=u.dtype)
+        du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
+        dA = torch.zeros_like(A)
+        dB, dC = torch.zeros_like(Bm, dtype=torch.float32), torch.zeros_like(Cm, dtype=torch.float32)
+        dD = torch.zeros_like(D) if D is not None else None
+        dbias = torch.zeros_like(bias) if bias is not None else None
+        with torch.cuda.device(g.device):
+            rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
+            _lib.check(rc, "ss2d_dirs_scatter")
+            rc = lib.ss2d_selective_scan_dir_bwd(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(Bm), _lib.ptr(Cm),
+                                                 _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
+                                                 _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
+                                                 _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
+                                                 ScanMergeFn.REV_MASK, _stream())
+            _lib.check(rc, "ss2d_selective_scan_dir_bwd")
+        du2 = du.view(batch, 2, 2, Dch, L).sum(2).view(batch, 2 * Dch, L)   # a direction and its reversal share u
+        cast = lambda t, d: None if t is None else t.to(d)  # noqa: E731
+        return (cast(du2, dts[0]), cast(ddelta, dts[1]), cast(dA, dts[2]), cast(dB, dts[3]), cast(dC, dts[4]),
+                cast(dD, dts[5]), cast(dbias, dts[6]), None, None)
+
+
+def scan_merge_fn(u2, delta, A, B, C, D, delta_bias, H, W):
+    """u2 (b, 2*d, l): row-major and column-major copies of x; delta (b, 4*d, l), A (4*d, n), B, C (b, 4, n, l), D,
+    delta_bias (4*d) in scan-group order (row-major, row-major reversed, column-major, column-major reversed), all in
+    un-reversed memory order.  softplus(delta + bias) as in SS2D.  Returns y (b, H, W, d) = CrossMerge of the scans."""
+    return ScanMergeFn.apply(u2, delta, A, B, C, D, delta_bias, H, W)

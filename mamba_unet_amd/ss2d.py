@@ -19,8 +19,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .selective_scan_interface import selective_scan_fn
-from .ss2d_ops import apply_linear, apply_norm, cross_merge, cross_scan, dwconv3x3_silu, outnorm_gate
+from .selective_scan_interface import scan_merge_fn, selective_scan_fn
+from .ss2d_ops import apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dwconv3x3_silu, outnorm_gate
 
 
 class DropPath(nn.Module):
@@ -123,8 +123,37 @@ class SS2D(nn.Module):
         """x (B, D, H, W) -> (B, H, W, D), normalised (the reference's swappable `forward_core`)."""
         return self.out_norm(self._scan_core(x)).to(x.dtype)
 
+    fused_directions = True   # class-wide switch: _scan_core_dirs instead of the literal cross_scan / scan / cross_merge
+
+    _GROUP_ORDER = (0, 2, 1, 3)   # scan group -> reference direction k (row-major, its reversal, column-major, its reversal)
+
+    def _scan_core_dirs(self, x: torch.Tensor):
+        """Same function as _scan_core with the direction permutations folded into the scan's loads and stores:
+        only the row-major and the column-major copy of x are materialised (2 of the 4 `xs` slices of :403-404), the
+        reversed directions read them backwards in place, x_proj runs once per orientation with the two directions'
+        weights stacked (M = 2*(R+2N)), and the scan output is merged without un-flipping."""
+        B, D, H, W = x.shape
+        L, N, R = H * W, self.d_state, self.dt_rank
+        Cx = R + 2 * N
+        # reference direction k = 2*rev + orientation  ->  scan group 2*orientation + rev: swap the two index bits
+        # (plain views + one small copy; no index tensor, so the step stays HIP-graph capturable)
+        def regroup(t):
+            return t.reshape(2, 2, *t.shape[1:]).transpose(0, 1).reshape(t.shape)
+        xs2 = dirs_scatter2(x)                                                                  # (B, 2, D, L)
+        w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
+        x_dbl = torch.matmul(w_cat.unsqueeze(0), xs2).view(B, 4, Cx, L)                         # group = 2*orientation + rev
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
+        dts = torch.matmul(regroup(self.dt_projs_weight).unsqueeze(0), dts)                     # (B, 4, D, L)
+        cast = (lambda t: t) if (self.bf16_scan_io and xs2.dtype == torch.bfloat16) else (lambda t: t.float())
+        A = regroup(-torch.exp(self.A_logs.float()).view(4, D, N)).reshape(4 * D, N)
+        return scan_merge_fn(cast(xs2).reshape(B, 2 * D, L), cast(dts).reshape(B, 4 * D, L), A,
+                             cast(Bs), cast(Cs), regroup(self.Ds.float().view(4, D)).reshape(-1),
+                             regroup(self.dt_projs_bias.float()).reshape(-1), H, W)
+
     def _scan_core(self, x: torch.Tensor):
         """forward_corev0 up to (not including) out_norm: x (B, D, H, W) -> merged y (B, H, W, D)."""
+        if self.fused_directions:
+            return self._scan_core_dirs(x)
         B, D, H, W = x.shape
         L, K, N, R = H * W, 4, self.d_state, self.dt_rank
         xs = cross_scan(x)                                                        # (B, 4, D, L)

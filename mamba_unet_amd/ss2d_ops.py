@@ -338,3 +338,37 @@ def apply_norm(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
             and module.bias is not None and x.is_cuda:
         return layer_norm(x, module.weight, module.bias, module.eps)
     return module(x)
+
+
+class _DirsScatter2(torch.autograd.Function):
+    """x (B, D, H, W) -> (B, 2, D, H*W): the row-major and the column-major copy only (layout MIRROR_FREE_2)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _need_gpu(x, "dirs_scatter2")
+        B, D, H, W = x.shape
+        io, code = _io(x)
+        xf = x.to(io).contiguous()
+        xs = torch.empty((B, 2, D, H * W), device=x.device, dtype=io)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().ss2d_dirs_scatter(code, 2, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, 0, _stream())
+        _lib.check(rc, "ss2d_dirs_scatter")
+        ctx.shape, ctx.in_dtype = (B, D, H, W), x.dtype
+        return xs.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, dxs):
+        B, D, H, W = ctx.shape
+        io, code = _io(dxs)
+        g = dxs.to(io).contiguous()
+        dx = torch.empty((B, D, H, W), device=g.device, dtype=io)
+        with torch.cuda.device(g.device):
+            rc = _lib.load().ss2d_dirs_gather(code, 2, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, 0, _stream())
+        _lib.check(rc, "ss2d_dirs_gather")
+        return dx.to(ctx.in_dtype)
+
+
+def dirs_scatter2(x: torch.Tensor) -> torch.Tensor:
+    """(B, D, H, W) -> (B, 2, D, H*W): x flattened row-major and column-major -- the two orientations of CrossScan
+    (mamba_sys.py:403); the two reversed directions (:404) are read from the same copies by the scan itself."""
+    return _DirsScatter2.apply(x)

@@ -251,3 +251,32 @@ def test_linear_with_bias_matches_f_linear():
     assert rel_l2(y.detach().cpu(), yr.detach().cpu()) < 1e-5
     for a, r in ((x, xr), (w, wr), (b, br)):
         assert rel_l2(a.grad.cpu(), r.grad.cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 8, 12, 20), (1, 24, 9, 5), (2, 96, 28, 28)])
+def test_fused_directions_equal_literal_path(B, C, H, W):
+    """SS2D with the direction permutations folded into the scan (rev_mask / shared u) against the literal
+    cross_scan -> scan -> cross_merge path of the same module: output and every gradient."""
+    from mamba_unet_amd import SS2D
+    torch.manual_seed(C + H)
+    m = SS2D(d_model=C).cuda()
+    with torch.no_grad():
+        m.A_logs.add_(torch.randn_like(m.A_logs) * 0.3)      # direction-specific parameters must stay with their direction
+        m.Ds.mul_(torch.rand_like(m.Ds) + 0.5)
+    x = torch.randn(B, H, W, C, device="cuda")
+    g = torch.randn(B, H, W, C, device="cuda")
+    res = {}
+    try:
+        for flag in (False, True):
+            SS2D.fused_directions = flag
+            xi = x.clone().requires_grad_(True)
+            m.zero_grad(set_to_none=True)
+            y = m(xi)
+            y.backward(g)
+            res[flag] = (y.detach(), xi.grad, {k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        SS2D.fused_directions = True
+    assert rel_l2(res[True][0].cpu(), res[False][0].cpu()) < 1e-5
+    assert rel_l2(res[True][1].cpu(), res[False][1].cpu()) < 2e-5
+    for k in res[True][2]:
+        assert rel_l2(res[True][2][k].cpu(), res[False][2][k].cpu()) < 5e-5, k
