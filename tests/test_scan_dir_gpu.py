@@ -1,0 +1,97 @@
+"""Direction-aware scan entry points (ss2d_selective_scan_dir_fwd/_bwd: rev_mask, u_groups) and the mirror-free
+direction layouts of the cross kernels, against the oracle pipeline cross_scan -> sequential scan -> cross_merge
+(mamba_sys.py:403-449) evaluated in fp64 on the CPU."""
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(xs2, delta, A, Bm, Cm, Dv, bias, H, W):
+    """Inputs in scan-group order (row-major, row-major reversed, column-major, column-major reversed) and
+    UN-reversed memory order, as scan_merge_fn takes them.  Returns the merged y (B, H, W, D)."""
+    from oracle.selective_scan_ref import selective_scan_ref
+    B, _, L = delta.shape
+    D = xs2.shape[1] // 2
+    x2 = xs2.view(B, 2, D, L)
+    flip = lambda t: t.flip(-1)  # noqa: E731
+    u = torch.stack([x2[:, 0], flip(x2[:, 0]), x2[:, 1], flip(x2[:, 1])], 1).reshape(B, 4 * D, L)     # scan order
+    d4 = delta.view(B, 4, D, L)
+    dl = torch.stack([d4[:, 0], flip(d4[:, 1]), d4[:, 2], flip(d4[:, 3])], 1).reshape(B, 4 * D, L)
+    Bs = torch.stack([Bm[:, 0], flip(Bm[:, 1]), Bm[:, 2], flip(Bm[:, 3])], 1)
+    Cs = torch.stack([Cm[:, 0], flip(Cm[:, 1]), Cm[:, 2], flip(Cm[:, 3])], 1)
+    out = selective_scan_ref(u, dl, A, Bs, Cs, Dv, None, bias, True, compute_dtype=torch.float64).view(B, 4, D, L)
+    rm = out[:, 0] + flip(out[:, 1])                                    # (B, D, L) row-major order
+    cm = (out[:, 2] + flip(out[:, 3])).view(B, D, W, H).transpose(2, 3).reshape(B, D, L)
+    return (rm + cm).view(B, D, H, W).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,D,H,W,N,dtype", [(2, 8, 5, 7, 16, torch.float32), (1, 20, 12, 8, 16, torch.float32),
+                                             (2, 32, 28, 28, 16, torch.float32), (1, 12, 16, 20, 5, torch.float32),
+                                             (2, 32, 28, 28, 16, torch.bfloat16), (1, 8, 9, 13, 16, torch.bfloat16)])
+def test_scan_merge_fn_matches_oracle_pipeline(B, D, H, W, N, dtype):
+    from mamba_unet_amd import scan_merge_fn
+    L = H * W
+    gen = torch.Generator().manual_seed(H * 31 + W)
+    r = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    q = (lambda t: t.to(dtype).float()) if dtype == torch.bfloat16 else (lambda t: t)
+    inp = {"xs2": q(r(B, 2 * D, L)), "delta": q(r(B, 4 * D, L) * 0.5), "A": -torch.exp(r(4 * D, N) * 0.5),
+           "B": q(r(B, 4, N, L)), "C": q(r(B, 4, N, L)), "D": torch.rand(4 * D, generator=gen) + 0.5,
+           "bias": r(4 * D) * 0.2 - 2.0}
+    gy = q(r(B, H, W, D))
+    ref = {k: v.clone().double().requires_grad_(True) for k, v in inp.items()}
+    yr = _oracle(ref["xs2"], ref["delta"], ref["A"], ref["B"], ref["C"], ref["D"], ref["bias"], H, W)
+    yr.backward(gy.double())
+    act = ("xs2", "delta", "B", "C")
+    dev = {k: (v.cuda().to(dtype) if k in act else v.cuda()).requires_grad_(True) for k, v in inp.items()}
+    y = scan_merge_fn(dev["xs2"], dev["delta"], dev["A"], dev["B"], dev["C"], dev["D"], dev["bias"], H, W)
+    assert y.dtype == dtype and y.shape == (B, H, W, D)
+    y.backward(gy.cuda().to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(y.detach().float().cpu(), yr.detach()) < tol
+    for k in inp:
+        t = tol if k in act else (1e-5 if dtype == torch.float32 else 1e-4)
+        err = rel_l2(dev[k].grad.float().cpu(), ref[k].grad)
+        assert err < t, (k, err)
+
+
+@pytest.mark.parametrize("B,D,H,W", [(2, 5, 3, 7), (1, 40, 16, 12), (1, 33, 56, 56)])
+def test_mirror_free_layouts_bit_exact(B, D, H, W):
+    """dirs_scatter (2 slots) / dirs_gather (4 and 2 slots, mirror-free) are permutations / sums in the reference's
+    order: bit-exact against index arithmetic."""
+    import ctypes
+    from mamba_unet_amd import _lib
+    lib, P = _lib.load(), _lib.ptr
+    L = H * W
+    gen = torch.Generator().manual_seed(D)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x = torch.randn(B, D, H, W, generator=gen)
+    xs2 = torch.empty(B, 2, D, L, device="cuda")
+    xd = x.cuda()
+    _lib.check(lib.ss2d_dirs_scatter(0, 2, P(xd), P(xs2), B, D, H, W, 0, st), "scatter")
+    assert torch.equal(xs2[:, 0].cpu(), x.reshape(B, D, L))
+    assert torch.equal(xs2[:, 1].cpu(), x.transpose(2, 3).reshape(B, D, L))
+    ys = torch.randn(B, 4, D, L, generator=gen)
+    yd, y = ys.cuda(), torch.empty(B, H, W, D, device="cuda")
+    _lib.check(lib.ss2d_dirs_gather(0, 1, P(yd), P(y), B, D, H, W, 1, st), "gather4")
+    cm = lambda t: t.view(B, D, W, H).transpose(2, 3).reshape(B, D, L)  # noqa: E731
+    want = ((ys[:, 0] + ys[:, 1]) + cm(ys[:, 2])) + cm(ys[:, 3])
+    assert torch.equal(y.cpu(), want.view(B, D, H, W).permute(0, 2, 3, 1))
+    y2 = torch.empty(B, D, L, device="cuda")
+    _lib.check(lib.ss2d_dirs_gather(0, 2, P(yd[:, :2].contiguous()), P(y2), B, D, H, W, 0, st), "gather2")
+    assert torch.equal(y2.cpu(), ys[:, 0] + cm(ys[:, 1]))
+
+
+def test_dir_entry_points_reject_bad_grouping():
+    import ctypes
+    from mamba_unet_amd import _lib
+    lib, P = _lib.load(), _lib.ptr
+    t = torch.zeros(64, device="cuda")
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = lib.ss2d_selective_scan_dir_fwd(0, P(t), P(t), P(t), P(t), P(t), None, None, None, P(t), None, None,
+                                         1, 4, 4, 1, 4, 1, 3, 0, st)        # u_groups 3 does not divide 4 groups
+    assert rc < 0 and b"u_groups" in lib.ss2d_last_error()
+    rc = lib.ss2d_dirs_gather(0, 9, P(t), P(t), 1, 1, 2, 2, 0, st)
+    assert rc < 0 and b"layout" in lib.ss2d_last_error()
