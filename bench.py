@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # passes of this very command, 2 x FETCH_SIZE x 1024 (gfx950 tallies a 128-byte read request as 64 bytes) +
 # WRITE_SIZE x 1024, averaged over the dispatches -- tools/profile_round.sh, profiles/r01/bench_pmc_summary_final.txt.
 # Valid for the config-2 shapes of this file only; re-measure when a kernel's memory behaviour changes.
-PMC_TRAFFIC_BYTES = {"scan_fwd_f32_kernel": 776671024, "scan_bwd_f32_kernel": 1337586368}
+PMC_TRAFFIC_BYTES = {"scan_fwd_kernel<float>": 776664552, "scan_bwd_kernel<float>": 1337427072}
 
 
 def algorithmic_bytes(batch):
@@ -162,7 +162,7 @@ def main():
             gy.backward(gdout.to(dev))
             rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())  # noqa: E731
             parity = {"out": rel(gy.detach(), cy), **{"d" + k: rel(gi[k].grad, leaves[k].grad) for k in gi}}
-        dominant_us, dominant_bytes, dominant = (bwd_us, bb, "scan_bwd_f32_kernel") if bwd_us >= fwd_us else (fwd_us, fb, "scan_fwd_f32_kernel")
+        dominant_us, dominant_bytes, dominant = (bwd_us, bb, "scan_bwd_kernel<float>") if bwd_us >= fwd_us else (fwd_us, fb, "scan_fwd_kernel<float>")
         achieved = dominant_bytes / (dominant_us * 1e-6) / 1e9
         line = {
             "metric": "SS2D selective-scan fwd+bwd achieved HBM GB/s (algorithmic bytes / time)",
