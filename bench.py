@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 BATCH, K, D, L, N = 24, 4, 192, 3136, 16
 KD = K * D
-CPU_SLICES = 12         # bounded CPU sample: ~10-30 s of host time
+CPU_SLICES = 24         # bounded CPU sample: the whole config-2 batch once, ~10 s of host time
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # HBM bytes per launch from the PMC counters (cannot be collected inside this process): separate rocprofv3 --pmc
 # passes of this very command, 2 x FETCH_SIZE x 1024 (gfx950 tallies a 128-byte read request as 64 bytes) +
@@ -46,7 +46,7 @@ def algorithmic_bytes(batch):
 
 def cpu_baseline():
     """The reference's CPU path (sequential selective_scan_ref in PyTorch, restated in oracle/) timed
-    on this host: forward + autograd backward on ONE slice (B=1) of the same workload."""
+    on this host: forward + autograd backward on CPU_SLICES slices of the same workload."""
     from oracle.selective_scan_ref import selective_scan_ref
     from oracle.ss2d_ref import make_scan_inputs
     cores = min(16, os.cpu_count() or 1)
