@@ -123,6 +123,13 @@ int ss2d_dwconv3x3_silu_bwd(int dtype, const void *x, const float *w, const floa
                             void *dx, float *dw, float *dbias, int B, int D, int H, int W, int channel_last_in,
                             int ldx, int lddx, void *stream);
 
+/* dt_proj forward (mamba_sys.py:420, weight :319-327): out[b,g,d,l] = sum_r w[g,d,r] * x[b,g,r,l], R = dt_rank in
+ * {6, 12} (stages 0 and 1 of Mamba-UNet; other ranks: use a library GEMM).  x is read in place from the first R rows
+ * of every (b, g) block of the x_proj output (x_bg_stride elements between blocks, >= R*L); w (G, D, R) fp32;
+ * out (batch, G, D, L) dense.  L and x_bg_stride multiples of 4. */
+int ss2d_dt_proj_fwd(int dtype, const void *x, const float *w, void *out, int batch, int ngroups, int D, int R, int L,
+                     long long x_bg_stride, void *stream);
+
 /* Weight gradient of the bias-free in_proj / out_proj Linears (mamba_sys.py:298, :337; used :555, :562; the
  * reference gets it from autograd of nn.Linear): C[m][n] += sum_r A[r][m] * B[r][n] with A = dL/d(output)
  * (rows x M, row stride lda), B = the Linear's input (rows x N, row stride ldb), rows = batch*H*W tokens,

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import scan_merge_fn, selective_scan_fn
-from .ss2d_ops import apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dwconv3x3_silu, outnorm_gate
+from .ss2d_ops import apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate
 
 
 class DropPath(nn.Module):
@@ -143,7 +143,7 @@ class SS2D(nn.Module):
         w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
         x_dbl = torch.matmul(w_cat.unsqueeze(0), xs2).view(B, 4, Cx, L)                         # group = 2*orientation + rev
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
-        dts = torch.matmul(regroup(self.dt_projs_weight).unsqueeze(0), dts)                     # (B, 4, D, L)
+        dts = dt_proj(dts, regroup(self.dt_projs_weight))                                       # (B, 4, D, L)
         cast = (lambda t: t) if (self.bf16_scan_io and xs2.dtype == torch.bfloat16) else (lambda t: t.float())
         A = regroup(-torch.exp(self.A_logs.float()).view(4, D, N)).reshape(4 * D, N)
         return scan_merge_fn(cast(xs2).reshape(B, 2 * D, L), cast(dts).reshape(B, 4 * D, L), A,

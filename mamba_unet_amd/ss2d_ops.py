@@ -372,3 +372,43 @@ def dirs_scatter2(x: torch.Tensor) -> torch.Tensor:
     """(B, D, H, W) -> (B, 2, D, H*W): x flattened row-major and column-major -- the two orientations of CrossScan
     (mamba_sys.py:403); the two reversed directions (:404) are read from the same copies by the scan itself."""
     return _DirsScatter2.apply(x)
+
+
+class _DtProj(torch.autograd.Function):
+    """dts = einsum("bgrl,gdr->bgdl") (mamba_sys.py:420): forward on the streaming HIP kernel, gradients on library
+    GEMMs (dX = W^T g, dW = sum_b g x^T)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        B, G, R, L = x.shape
+        D = weight.shape[1]
+        io, code = _io(x)
+        xs = x.to(io)
+        if not (xs.stride(3) == 1 and xs.stride(2) == L and xs.stride(0) == G * xs.stride(1)):
+            xs = xs.contiguous()
+        w32 = weight.float().contiguous()
+        out = torch.empty((B, G, D, L), device=x.device, dtype=io)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().ss2d_dt_proj_fwd(code, _lib.ptr(xs), _lib.ptr(w32), _lib.ptr(out), B, G, D, R, L,
+                                              xs.stride(1), _stream())
+        _lib.check(rc, "ss2d_dt_proj_fwd")
+        ctx.save_for_backward(xs, weight)
+        ctx.x_dtype = x.dtype
+        return out.to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, weight = ctx.saved_tensors
+        g = g.to(xs.dtype)
+        w = weight.to(xs.dtype)
+        dx = torch.matmul(w.transpose(1, 2).unsqueeze(0), g) if ctx.needs_input_grad[0] else None
+        dw = torch.matmul(g, xs.transpose(2, 3)).sum(0).to(weight.dtype) if ctx.needs_input_grad[1] else None
+        return None if dx is None else dx.to(ctx.x_dtype), dw
+
+
+def dt_proj(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """x (B, G, R, L) (may be the first R rows of each block of x_dbl), weight (G, D, R) -> (B, G, D, L)."""
+    B, G, R, L = x.shape
+    if x.is_cuda and R in (6, 12) and L % 4 == 0 and x.stride(3) == 1 and x.stride(1) % 4 == 0 and x.data_ptr() % 16 == 0:
+        return _DtProj.apply(x, weight)
+    return torch.matmul(weight.unsqueeze(0), x)

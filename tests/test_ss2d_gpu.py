@@ -280,3 +280,26 @@ def test_fused_directions_equal_literal_path(B, C, H, W):
     assert rel_l2(res[True][1].cpu(), res[False][1].cpu()) < 2e-5
     for k in res[True][2]:
         assert rel_l2(res[True][2][k].cpu(), res[False][2][k].cpu()) < 5e-5, k
+
+
+@pytest.mark.parametrize("B,G,D,R,L,dtype", [(2, 4, 192, 6, 3136, torch.float32), (1, 4, 384, 12, 784, torch.float32),
+                                             (3, 4, 16, 6, 20, torch.float32), (2, 4, 192, 6, 3136, torch.bfloat16)])
+def test_dt_proj_kernel(B, G, D, R, L, dtype):
+    """dts = einsum('bgrl,gdr->bgdl') on the streaming kernel, x read in place from the first R rows of x_dbl."""
+    from mamba_unet_amd.ss2d_ops import dt_proj
+    gen = torch.Generator().manual_seed(L)
+    Cx = R + 32
+    x_dbl = torch.randn(B, G, Cx, L, generator=gen).to(dtype)
+    w = torch.randn(G, D, R, generator=gen) * 0.3
+    go = torch.randn(B, G, D, L, generator=gen).to(dtype)
+    xr, wr = x_dbl.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = torch.einsum("bgrl,gdr->bgdl", xr[:, :, :R], wr)
+    ref.backward(go.double())
+    xd, wd = x_dbl.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    out = dt_proj(xd[:, :, :R], wd)
+    assert out.dtype == dtype
+    out.backward(go.cuda())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(out.detach().float().cpu(), ref.detach()) < tol
+    assert rel_l2(xd.grad[:, :, :R].float().cpu(), xr.grad[:, :, :R]) < tol
+    assert rel_l2(wd.grad.cpu(), wr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
