@@ -98,6 +98,13 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const ConvParams p
     __shared__ float sg[GH * GW * CS];       // ds; reused as the dx staging tile for the channel-last write
     int b, d0, h0, w0;
     conv_tile<CD>(p, b, d0, h0, w0);
+    __shared__ float swt[CD * 10];           // 9 taps + bias per channel: read per element below, keep them off the vector memory path
+    for (int i = threadIdx.x; i < CD * 10; i += 256) {
+        const int d = i / 10, j = i - d * 10;
+        float v = 0.0f;
+        if (d0 + d < p.D) v = j < 9 ? p.w[(size_t)(d0 + d) * 9 + j] : (p.bias ? p.bias[d0 + d] : 0.0f);
+        swt[i] = v;
+    }
     load_x_tile<CL, 2, CD, IO>(p, sx, b, d0, h0, w0);
     __syncthreads();
     const int tid = threadIdx.x;
@@ -107,12 +114,12 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const ConvParams p
         const int h = h0 - 1 + hh, w = w0 - 1 + ww;
         float g = 0.0f;
         if (d0 + d < p.D && h >= 0 && h < p.H && w >= 0 && w < p.W) {
-            float o = p.bias ? p.bias[d0 + d] : 0.0f;
+            float o = swt[d * 10 + 9];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    o = fmaf(p.w[(size_t)(d0 + d) * 9 + a * 3 + c], sx[((hh + a) * XW + ww + c) * CS + d], o);
+                    o = fmaf(swt[d * 10 + a * 3 + c], sx[((hh + a) * XW + ww + c) * CS + d], o);
             const float sgm = sigmoidf_fast(o);
             g = ld1(static_cast<const IO *>(p.dy) + (((size_t)b * p.D + d0 + d) * p.H + h) * p.W + w) * (sgm * (1.0f + o * (1.0f - sgm)));
         }
@@ -127,7 +134,7 @@ __global__ __launch_bounds__(256) void dwconv_silu_bwd_kernel(const ConvParams p
         const bool dok = d0 + d < p.D;
         float k[9], accw[9], accb = 0.0f;
 #pragma unroll
-        for (int j = 0; j < 9; ++j) { k[j] = dok ? p.w[(size_t)(d0 + d) * 9 + j] : 0.0f; accw[j] = 0.0f; }
+        for (int j = 0; j < 9; ++j) { k[j] = swt[d * 10 + j]; accw[j] = 0.0f; }
 #pragma unroll
         for (int h = 0; h < TH; ++h) {
             const bool ok = dok && (h0 + h < p.H) && (w0 + wl < p.W);
