@@ -4,7 +4,7 @@
 //   scan : xs[b,0,d,p] = xs[b,1,d,q] = xs[b,2,d,L-1-p] = xs[b,3,d,L-1-q] = x[b,d,h,w]
 //   merge: y[b,d,h,w] = ys[b,0,d,p] + ys[b,1,d,q] + ys[b,2,d,L-1-p] + ys[b,3,d,L-1-q]
 // The two are adjoint, so cross_scan_bwd = merge and cross_merge_bwd = scan.
-// A workgroup owns a 3-D tile (32 channels x 16 rows x 16 cols) held in LDS: row-major directions are
+// A workgroup owns a 3-D tile (32 channels x 16 rows x 16 cols; 128 x 8 x 8 for images up to 8x8) held in LDS: row-major directions are
 // touched with w on the fast lanes, column-major ones with h on the fast lanes (64-byte runs either way),
 // and a channel-last side (B,H,W,D) with d on the fast lanes (128-byte runs).
 #include "ss2d_common.h"
@@ -12,9 +12,15 @@
 
 namespace {
 
-constexpr int TD = 32, TH = 16, TW = 16;
-constexpr int SW = TW + 1;              // padded w stride
-constexpr int SD = TH * SW + 1;         // padded channel stride (odd -> conflict-free channel-fast access)
+// Tile held in LDS: TD channels x TH rows x TW cols, padded w stride and an odd channel stride (conflict-free
+// channel-fast access).  32x16x16 in general; 128x8x8 for images of at most 8x8 (the 7x7 stage), where a 16x16
+// tile would be 80 % padding.
+template <int TD_, int TH_, int TW_>
+struct Tile {
+    static constexpr int TD = TD_, TH = TH_, TW = TW_, SW = TW_ + 1, SD = TH_ * SW + 1, N = TD_ * TH_ * TW_;
+};
+using TileBig = Tile<32, 16, 16>;
+using TileSmall = Tile<128, 8, 8>;
 
 struct CrossParams {
     const void *in;    // scan: x ; merge: ys   (IO type: fp32 or bf16)
@@ -26,45 +32,68 @@ struct CrossParams {
     int nslots, rmB, cmA, cmB, revB;
 };
 
+template <typename T>
 __device__ __forceinline__ void tile_coords(const CrossParams &p, int &b, int &d0, int &h0, int &w0) {
     int blk = blockIdx.x;
     const int tw = blk % p.tiles_w; blk /= p.tiles_w;
     const int th = blk % p.tiles_h; blk /= p.tiles_h;
     const int td = blk % p.tiles_d; b = blk / p.tiles_d;
-    d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+    d0 = td * T::TD; h0 = th * T::TH; w0 = tw * T::TW;
 }
 
+// Index decoders of the three access phases (E elements per lane along the fast axis):
+//   row phase: w fast, then h, then d      col phase: h fast, then w, then d      channel phase: d fast, then w, then h
+template <typename T, int E> __device__ __forceinline__ void dec_row(int i, int &d, int &h, int &w) {
+    w = (i % (T::TW / E)) * E; h = (i / (T::TW / E)) % T::TH; d = i / (T::TW / E * T::TH);
+}
+template <typename T, int E> __device__ __forceinline__ void dec_col(int i, int &d, int &h, int &w) {
+    h = (i % (T::TH / E)) * E; w = (i / (T::TH / E)) % T::TW; d = i / (T::TH / E * T::TW);
+}
+template <typename T, int E> __device__ __forceinline__ void dec_chn(int i, int &d, int &h, int &w) {
+    d = (i % (T::TD / E)) * E; const int pos = i / (T::TD / E); w = pos % T::TW; h = pos / T::TW;
+}
+
+// All global reads below are unconditional, with coordinates clamped into the tensor, and are issued a batch
+// (UB) at a time before the LDS stores that consume them: a read under `if (inside)` is sunk into its branch
+// with a full wait, i.e. one HBM round trip per loop trip.  Tile padding then holds duplicates of edge
+// elements; it is never written out (every global write keeps its bounds check).
+constexpr int UB = 8;
+
 // x side is channel-last (B,H,W,D) when CL, else (B,D,H,W)
-template <bool CL, typename IO>
+template <bool CL, typename IO, typename T>
 __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
-    __shared__ float s[TD * SD];
+    __shared__ float s[T::TD * T::SD];
     const IO *__restrict__ in = static_cast<const IO *>(p.in);
     IO *__restrict__ out = static_cast<IO *>(p.out);
     int b, d0, h0, w0;
-    tile_coords(p, b, d0, h0, w0);
+    tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
     const size_t L = (size_t)H * W;
-    if (CL) {
-        for (int i = tid; i < TD * TH * TW; i += 256) {
-            const int d = i & (TD - 1), pos = i >> 5, w = pos & (TW - 1), h = pos >> 4;
-            float v = 0.0f;
-            if (d0 + d < D && h0 + h < H && w0 + w < W) v = ld1(in + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d);
-            s[d * SD + h * SW + w] = v;
+    constexpr int NIT = T::N / 256;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += UB) {
+        float v[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            int d, h, w;
+            if (CL) dec_chn<T, 1>(tid + (it0 + u) * 256, d, h, w); else dec_row<T, 1>(tid + (it0 + u) * 256, d, h, w);
+            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - 1);
+            v[u] = CL ? ld1(in + (((size_t)b * H + hc) * W + wc) * D + dc) : ld1(in + (((size_t)b * D + dc) * H + hc) * W + wc);
         }
-    } else {
-        for (int i = tid; i < TD * TH * TW; i += 256) {
-            const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
-            float v = 0.0f;
-            if (d0 + d < D && h0 + h < H && w0 + w < W) v = ld1(in + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w);
-            s[d * SD + h * SW + w] = v;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            int d, h, w;
+            if (CL) dec_chn<T, 1>(tid + (it0 + u) * 256, d, h, w); else dec_row<T, 1>(tid + (it0 + u) * 256, d, h, w);
+            s[d * T::SD + h * T::SW + w] = v[u];
         }
     }
     __syncthreads();
     // row-major directions 0 and 2: w on the fast lanes
-    for (int i = tid; i < TD * TH * TW; i += 256) {
-        const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
+    for (int i = tid; i < T::N; i += 256) {
+        int d, h, w;
+        dec_row<T, 1>(i, d, h, w);
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            const float v = s[d * SD + h * SW + w];
+            const float v = s[d * T::SD + h * T::SW + w];
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
             IO *o0 = out + (((size_t)b * p.nslots + 0) * D + d0 + d) * L;
             st1(o0 + pp, v);
@@ -72,10 +101,11 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
         }
     }
     // column-major directions 1 and 3: h on the fast lanes
-    for (int i = tid; i < TD * TH * TW; i += 256) {
-        const int h = i & (TH - 1), w = (i >> 4) & (TW - 1), d = i >> 8;
+    for (int i = tid; i < T::N; i += 256) {
+        int d, h, w;
+        dec_col<T, 1>(i, d, h, w);
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            const float v = s[d * SD + h * SW + w];
+            const float v = s[d * T::SD + h * T::SW + w];
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
             IO *o1 = out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L;
             st1(o1 + q, v);
@@ -85,50 +115,68 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
 }
 
 // sums in fp32 (LDS), one rounding at the end for bf16 output
-template <bool CL, typename IO>
+template <bool CL, typename IO, typename T>
 __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
-    __shared__ float s[TD * SD];
+    __shared__ float s[T::TD * T::SD];
     const IO *__restrict__ in = static_cast<const IO *>(p.in);
     IO *__restrict__ out = static_cast<IO *>(p.out);
     int b, d0, h0, w0;
-    tile_coords(p, b, d0, h0, w0);
+    tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
     const size_t L = (size_t)H * W;
-    for (int i = tid; i < TD * TH * TW; i += 256) {
-        const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
-        float v = 0.0f;
-        if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            const IO *i0 = in + (((size_t)b * p.nslots + 0) * D + d0 + d) * L;
-            v = ld1(i0 + pp);
-            if (p.nslots == 4) v += ld1(in + (((size_t)b * 4 + p.rmB) * D + d0 + d) * L + (p.revB ? L - 1 - pp : pp));
+    constexpr int NIT = T::N / 256;
+    const bool four = p.nslots == 4;
+    const int sB = four ? 4 : p.nslots;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += UB) {
+        float v[UB], v2[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            int d, h, w;
+            dec_row<T, 1>(tid + (it0 + u) * 256, d, h, w);
+            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - 1);
+            const size_t pp = (size_t)hc * W + wc;
+            v[u] = ld1(in + (((size_t)b * p.nslots + 0) * D + dc) * L + pp);
+            // with two slots rmB is 0: the same element again, not added
+            v2[u] = ld1(in + (((size_t)b * sB + p.rmB) * D + dc) * L + (p.revB ? L - 1 - pp : pp));
         }
-        s[d * SD + h * SW + w] = v;
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            int d, h, w;
+            dec_row<T, 1>(tid + (it0 + u) * 256, d, h, w);
+            s[d * T::SD + h * T::SW + w] = four ? v[u] + v2[u] : v[u];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < TD * TH * TW; i += 256) {
-        const int h = i & (TH - 1), w = (i >> 4) & (TW - 1), d = i >> 8;
-        if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            const IO *i1 = in + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L;
-            // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
-            float acc = s[d * SD + h * SW + w] + ld1(i1 + q);
-            if (p.nslots == 4) acc += ld1(in + (((size_t)b * 4 + p.cmB) * D + d0 + d) * L + (p.revB ? L - 1 - q : q));
-            s[d * SD + h * SW + w] = acc;
+#pragma unroll 1
+    for (int it0 = 0; it0 < NIT; it0 += UB) {
+        float v1[UB], v3[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            int d, h, w;
+            dec_col<T, 1>(tid + (it0 + u) * 256, d, h, w);
+            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - 1);
+            const size_t q = (size_t)wc * H + hc;
+            v1[u] = ld1(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * L + q);
+            v3[u] = ld1(in + (((size_t)b * sB + p.cmB) * D + dc) * L + (p.revB ? L - 1 - q : q));
+        }
+        // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            int d, h, w;
+            dec_col<T, 1>(tid + (it0 + u) * 256, d, h, w);
+            const float acc = s[d * T::SD + h * T::SW + w] + v1[u];
+            s[d * T::SD + h * T::SW + w] = four ? acc + v3[u] : acc;
         }
     }
     __syncthreads();
-    if (CL) {
-        for (int i = tid; i < TD * TH * TW; i += 256) {
-            const int d = i & (TD - 1), pos = i >> 5, w = pos & (TW - 1), h = pos >> 4;
-            if (d0 + d < D && h0 + h < H && w0 + w < W)
-                st1(out + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d, s[d * SD + h * SW + w]);
-        }
-    } else {
-        for (int i = tid; i < TD * TH * TW; i += 256) {
-            const int w = i & (TW - 1), h = (i >> 4) & (TH - 1), d = i >> 8;
-            if (d0 + d < D && h0 + h < H && w0 + w < W)
-                st1(out + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w, s[d * SD + h * SW + w]);
+    for (int i = tid; i < T::N; i += 256) {
+        int d, h, w;
+        if (CL) dec_chn<T, 1>(i, d, h, w); else dec_row<T, 1>(i, d, h, w);
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            const float v = s[d * T::SD + h * T::SW + w];
+            if (CL) st1(out + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d, v);
+            else st1(out + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w, v);
         }
     }
 }
@@ -139,39 +187,42 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
 // the host falls back to the scalar kernels otherwise (14x14 and 7x7 stages).
 __device__ __forceinline__ f4 rev4(f4 v) { return f4{v.w, v.z, v.y, v.x}; }
 
-template <bool CL, typename IO>
+template <bool CL, typename IO, typename T>
 __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p) {
-    __shared__ float s[TD * SD];
+    __shared__ float s[T::TD * T::SD];
     const IO *__restrict__ in = static_cast<const IO *>(p.in);
     IO *__restrict__ out = static_cast<IO *>(p.out);
     int b, d0, h0, w0;
-    tile_coords(p, b, d0, h0, w0);
+    tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
     const size_t L = (size_t)H * W;
-    if (CL) {  // 4 consecutive channels per lane
-        for (int i = tid; i < TD * TH * TW / 4; i += 256) {
-            const int d = (i & 7) * 4, pos = i >> 3, w = pos & (TW - 1), h = pos >> 4;
-            f4 v = f4{0, 0, 0, 0};
-            if (d0 + d < D && h0 + h < H && w0 + w < W) v = ld4(in + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d);
+    constexpr int NIT = T::N / 4 / 256;
+    {
+        f4 v[NIT];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[(d + e) * SD + h * SW + w] = v[e];
+        for (int it = 0; it < NIT; ++it) {
+            int d, h, w;
+            if (CL) dec_chn<T, 4>(tid + it * 256, d, h, w); else dec_row<T, 4>(tid + it * 256, d, h, w);
+            // 4 consecutive channels (CL) or columns per lane; sizes are multiples of 4, so a group is inside or outside as a whole
+            const int dc = min(d0 + d, CL ? D - 4 : D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, CL ? W - 1 : W - 4);
+            v[it] = CL ? ld4(in + (((size_t)b * H + hc) * W + wc) * D + dc) : ld4(in + (((size_t)b * D + dc) * H + hc) * W + wc);
         }
-    } else {   // 4 consecutive columns per lane
-        for (int i = tid; i < TD * TH * TW / 4; i += 256) {
-            const int w = (i & 3) * 4, h = (i >> 2) & (TH - 1), d = i >> 6;
-            f4 v = f4{0, 0, 0, 0};
-            if (d0 + d < D && h0 + h < H && w0 + w < W) v = ld4(in + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[d * SD + h * SW + w + e] = v[e];
+        for (int it = 0; it < NIT; ++it) {
+            int d, h, w;
+            if (CL) dec_chn<T, 4>(tid + it * 256, d, h, w); else dec_row<T, 4>(tid + it * 256, d, h, w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[(CL ? d + e : d) * T::SD + h * T::SW + (CL ? w : w + e)] = v[it][e];
         }
     }
     __syncthreads();
-    for (int i = tid; i < TD * TH * TW / 4; i += 256) {   // directions 0 and 2: runs along w
-        const int w = (i & 3) * 4, h = (i >> 2) & (TH - 1), d = i >> 6;
+    for (int i = tid; i < T::N / 4; i += 256) {   // directions 0 and 2: runs along w
+        int d, h, w;
+        dec_row<T, 4>(i, d, h, w);
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             f4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = s[d * SD + h * SW + w + e];
+            for (int e = 0; e < 4; ++e) v[e] = s[d * T::SD + h * T::SW + w + e];
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
             st4(out + (((size_t)b * p.nslots + 0) * D + d0 + d) * L + pp, v);
             if (p.nslots == 4) {
@@ -180,12 +231,13 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
             }
         }
     }
-    for (int i = tid; i < TD * TH * TW / 4; i += 256) {   // directions 1 and 3: runs along h
-        const int h = (i & 3) * 4, w = (i >> 2) & (TW - 1), d = i >> 6;
+    for (int i = tid; i < T::N / 4; i += 256) {   // directions 1 and 3: runs along h
+        int d, h, w;
+        dec_col<T, 4>(i, d, h, w);
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             f4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = s[d * SD + (h + e) * SW + w];
+            for (int e = 0; e < 4; ++e) v[e] = s[d * T::SD + (h + e) * T::SW + w];
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
             st4(out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L + q, v);
             if (p.nslots == 4) {
@@ -196,70 +248,90 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
     }
 }
 
-template <bool CL, typename IO>
+template <bool CL, typename IO, typename T>
 __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams p) {
-    __shared__ float s[TD * SD];
+    __shared__ float s[T::TD * T::SD];
     const IO *__restrict__ in = static_cast<const IO *>(p.in);
     IO *__restrict__ out = static_cast<IO *>(p.out);
     int b, d0, h0, w0;
-    tile_coords(p, b, d0, h0, w0);
+    tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
     const size_t L = (size_t)H * W;
-    for (int i = tid; i < TD * TH * TW / 4; i += 256) {
-        const int w = (i & 3) * 4, h = (i >> 2) & (TH - 1), d = i >> 6;
-        f4 v = f4{0, 0, 0, 0};
-        if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            v = ld4(in + (((size_t)b * p.nslots + 0) * D + d0 + d) * L + pp);
-            if (p.nslots == 4) {
-                const IO *i2 = in + (((size_t)b * 4 + p.rmB) * D + d0 + d) * L;
-                v += p.revB ? rev4(ld4(i2 + (L - 4 - pp))) : ld4(i2 + pp);
-            }
+    constexpr int NIT = T::N / 4 / 256;
+    const bool four = p.nslots == 4;
+    const int sB = four ? 4 : p.nslots;
+    {
+        f4 v[NIT], v2[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int d, h, w;
+            dec_row<T, 4>(tid + it * 256, d, h, w);
+            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - 4);
+            const size_t pp = (size_t)hc * W + wc;
+            v[it] = ld4(in + (((size_t)b * p.nslots + 0) * D + dc) * L + pp);
+            const IO *i2 = in + (((size_t)b * sB + p.rmB) * D + dc) * L;
+            v2[it] = ld4(i2 + (p.revB ? L - 4 - pp : pp));
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) s[d * SD + h * SW + w + e] = v[e];
+        for (int it = 0; it < NIT; ++it) {
+            int d, h, w;
+            dec_row<T, 4>(tid + it * 256, d, h, w);
+            const f4 r = p.revB ? rev4(v2[it]) : v2[it];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[d * T::SD + h * T::SW + w + e] = four ? v[it][e] + r[e] : v[it][e];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < TD * TH * TW / 4; i += 256) {
-        const int h = (i & 3) * 4, w = (i >> 2) & (TW - 1), d = i >> 6;
-        if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            const f4 v1 = ld4(in + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L + q);
-            f4 v3 = f4{0, 0, 0, 0};
-            if (p.nslots == 4) {
-                const IO *i3 = in + (((size_t)b * 4 + p.cmB) * D + d0 + d) * L;
-                v3 = p.revB ? rev4(ld4(i3 + (L - 4 - q))) : ld4(i3 + q);
-            }
-            // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
+    {
+        f4 v1[NIT], v3[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int d, h, w;
+            dec_col<T, 4>(tid + it * 256, d, h, w);
+            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 4), wc = min(w0 + w, W - 1);
+            const size_t q = (size_t)wc * H + hc;
+            v1[it] = ld4(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * L + q);
+            const IO *i3 = in + (((size_t)b * sB + p.cmB) * D + dc) * L;
+            v3[it] = ld4(i3 + (p.revB ? L - 4 - q : q));
+        }
+        // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int d, h, w;
+            dec_col<T, 4>(tid + it * 256, d, h, w);
+            const f4 r = p.revB ? rev4(v3[it]) : v3[it];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float acc = s[d * SD + (h + e) * SW + w] + v1[e];
-                s[d * SD + (h + e) * SW + w] = p.nslots == 4 ? acc + v3[e] : acc;
+                const float acc = s[d * T::SD + (h + e) * T::SW + w] + v1[it][e];
+                s[d * T::SD + (h + e) * T::SW + w] = four ? acc + r[e] : acc;
             }
         }
     }
     __syncthreads();
-    if (CL) {
-        for (int i = tid; i < TD * TH * TW / 4; i += 256) {
-            const int d = (i & 7) * 4, pos = i >> 3, w = pos & (TW - 1), h = pos >> 4;
-            if (d0 + d < D && h0 + h < H && w0 + w < W) {
-                f4 v;
+    for (int i = tid; i < T::N / 4; i += 256) {
+        int d, h, w;
+        if (CL) dec_chn<T, 4>(i, d, h, w); else dec_row<T, 4>(i, d, h, w);
+        if (d0 + d < D && h0 + h < H && w0 + w < W) {
+            f4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = s[(d + e) * SD + h * SW + w];
-                st4(out + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d, v);
-            }
-        }
-    } else {
-        for (int i = tid; i < TD * TH * TW / 4; i += 256) {
-            const int w = (i & 3) * 4, h = (i >> 2) & (TH - 1), d = i >> 6;
-            if (d0 + d < D && h0 + h < H && w0 + w < W) {
-                f4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = s[d * SD + h * SW + w + e];
-                st4(out + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w, v);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = s[(CL ? d + e : d) * T::SD + h * T::SW + (CL ? w : w + e)];
+            if (CL) st4(out + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d, v);
+            else st4(out + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w, v);
         }
     }
+}
+
+template <typename T>
+void launch(bool merge, bool cl, bool vec, bool h, dim3 grid, hipStream_t s, const CrossParams &p) {
+    const dim3 block(256);
+#define SS2D_CROSS_LAUNCH(K)                                                                                         \
+    do {                                                                                                             \
+        if (cl) { if (h) hipLaunchKernelGGL((K<true, bf16, T>), grid, block, 0, s, p); else hipLaunchKernelGGL((K<true, float, T>), grid, block, 0, s, p); } \
+        else    { if (h) hipLaunchKernelGGL((K<false, bf16, T>), grid, block, 0, s, p); else hipLaunchKernelGGL((K<false, float, T>), grid, block, 0, s, p); } \
+    } while (0)
+    if (vec) { if (merge) SS2D_CROSS_LAUNCH(cross_merge_vec_kernel); else SS2D_CROSS_LAUNCH(cross_scan_vec_kernel); }
+    else     { if (merge) SS2D_CROSS_LAUNCH(cross_merge_kernel); else SS2D_CROSS_LAUNCH(cross_scan_kernel); }
+#undef SS2D_CROSS_LAUNCH
 }
 
 int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name) {
@@ -272,29 +344,17 @@ int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, i
     else if (layout == SS2D_DIRS_MIRROR_FREE_4) { p.nslots = 4; p.rmB = 1; p.cmA = 2; p.cmB = 3; p.revB = 0; }
     else if (layout == SS2D_DIRS_MIRROR_FREE_2) { p.nslots = 2; p.rmB = 0; p.cmA = 1; p.cmB = 1; p.revB = 0; }
     else { ss2d_set_error("%s: unknown direction layout %d", name, layout); return -7; }
-    p.tiles_h = (H + TH - 1) / TH; p.tiles_w = (W + TW - 1) / TW; p.tiles_d = (D + TD - 1) / TD;
+    const bool small = H <= TileSmall::TH && W <= TileSmall::TW;
+    const int td = small ? TileSmall::TD : TileBig::TD, th = small ? TileSmall::TH : TileBig::TH, tw = small ? TileSmall::TW : TileBig::TW;
+    p.tiles_h = (H + th - 1) / th; p.tiles_w = (W + tw - 1) / tw; p.tiles_d = (D + td - 1) / td;
     const long long n = (long long)B * p.tiles_d * p.tiles_h * p.tiles_w;
     if (n > 0x7fffffffLL) { ss2d_set_error("%s: grid too large", name); return -6; }
     hipStream_t s = (hipStream_t)stream;
-    const dim3 grid((unsigned)n), block(256);
+    const dim3 grid((unsigned)n);
     const bool h = dtype == SS2D_DTYPE_BF16;
     const uintptr_t amask = h ? 7 : 15;   // 4 elements
     const bool vec = (H % 4 == 0) && (W % 4 == 0) && (!cl || D % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & amask) == 0);
-    if (vec) {
-        if (merge) {
-            if (cl) { if (h) hipLaunchKernelGGL((cross_merge_vec_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_vec_kernel<true, float>), grid, block, 0, s, p); }
-            else    { if (h) hipLaunchKernelGGL((cross_merge_vec_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_vec_kernel<false, float>), grid, block, 0, s, p); }
-        } else {
-            if (cl) { if (h) hipLaunchKernelGGL((cross_scan_vec_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_scan_vec_kernel<true, float>), grid, block, 0, s, p); }
-            else    { if (h) hipLaunchKernelGGL((cross_scan_vec_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_scan_vec_kernel<false, float>), grid, block, 0, s, p); }
-        }
-    } else if (merge) {
-        if (cl) { if (h) hipLaunchKernelGGL((cross_merge_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_kernel<true, float>), grid, block, 0, s, p); }
-        else    { if (h) hipLaunchKernelGGL((cross_merge_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_merge_kernel<false, float>), grid, block, 0, s, p); }
-    } else {
-        if (cl) { if (h) hipLaunchKernelGGL((cross_scan_kernel<true, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_scan_kernel<true, float>), grid, block, 0, s, p); }
-        else    { if (h) hipLaunchKernelGGL((cross_scan_kernel<false, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((cross_scan_kernel<false, float>), grid, block, 0, s, p); }
-    }
+    if (small) launch<TileSmall>(merge, cl, vec, h, grid, s, p); else launch<TileBig>(merge, cl, vec, h, grid, s, p);
     const int rc = (int)hipGetLastError();
     if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
     return rc;
