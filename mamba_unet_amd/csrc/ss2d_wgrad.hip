@@ -9,10 +9,12 @@
 // the operand layout of v_mfma_f32_32x32x2_f32 (A: lane = m + 32k, B: lane = n + 32k, k = 0..1): a wave reads
 // two token rows with plain coalesced 128-byte runs straight into MFMA operands -- no LDS, no transposes.
 // A wave owns a 96 x 96 tile of C (3 x 3 MFMA tiles, 144 accumulator registers) for one slab of the token
-// axis; token slabs are spread over the whole chip and the partial tiles are added into C with one
-// fp32 atomic per element (C is zero-filled by the caller, like the other accumulated gradients of the ABI).
-// bf16 operands are widened on load (exact) and go through the same fp32 MFMA: the kernel stays bound by its
-// reads, and the gradient keeps fp32 products and sums.
+// axis; token slabs are spread over the whole chip, the four partial tiles of a workgroup are summed in LDS and
+// added into C with one fp32 atomic per element and workgroup (C is zero-filled by the caller, like the other
+// accumulated gradients of the ABI).
+// bf16 operands take v_mfma_f32_32x32x16_bf16 (second kernel below): bf16 products are exact in fp32, so the
+// gradient keeps fp32 products and sums, at 16x the MFMA rate; that kernel is bound by its reads
+// (stage 0 in_proj: 27 us of loop for 72 MB, plus ~10 us of reduction and atomics).
 #include <cstdlib>
 #include "ss2d_common.h"
 #include "../../include/ss2d.h"
@@ -28,9 +30,48 @@ struct WgradParams {
     const void *A, *B;
     float *C;
     long long rows;
-    int M, N, lda, ldb, ldc, tiles_m, tiles_n, tiles_pad, ksplit;
+    int M, N, lda, ldb, ldc, tiles_m, tiles_n, ksplit;
     long long slab;  // token rows per slab (even)
 };
+
+// The four waves of a workgroup own the same 96 x 96 tile of C and four consecutive token slabs.  Their partial
+// tiles are summed in LDS and leave as ONE set of global atomics per workgroup: the memory-side
+// atomic rate (~1.3 TB/s of added bytes chip-wide) otherwise bounds the kernel -- 1024 waves x 9216 elements took
+// about as long as reading the operands.
+__device__ __forceinline__ void tile_of_wave(const WgradParams &p, int wave, int &m0, int &n0, long long &r0, long long &r1) {
+    const int tiles = p.tiles_m * p.tiles_n;
+    // the tiles of one slab group run back to back on one XCD: they read the same B rows, which then come from that L2
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tile = lid % tiles;
+    const long long ks = (long long)(lid / tiles) * 4 + wave;
+    m0 = (tile / p.tiles_n) * WT; n0 = (tile % p.tiles_n) * WT;
+    r0 = ks * p.slab;
+    r1 = (r0 + p.slab < p.rows) ? r0 + p.slab : p.rows;   // r1 <= r0 for a slab past the end: that wave adds zeros
+}
+
+__device__ __forceinline__ void flush_tile(const WgradParams &p, float *tile, const f16v (&acc)[3][3], int m0, int n0, int lane, int wave) {
+    const int half = lane >> 5, l32 = lane & 31;
+    // The waves take turns (plain LDS stores, then read-add-write): float atomics on LDS cost 40 us here.
+    // accumulator register e of a 32x32 tile: row = 8*(e/4) + 4*(lane/32) + e%4, column = lane%32
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        float *t = tile + (32 * i + 8 * (e >> 2) + 4 * half + (e & 3)) * WT + 32 * j + l32;
+                        *t = w == 0 ? acc[i][j][e] : *t + acc[i][j][e];
+                    }
+        }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < WT * WT; i += 256) {
+        const int m = m0 + i / WT, n = n0 + i % WT;
+        if (m < p.M && n < p.N) atomicAdd(p.C + (size_t)m * p.ldc + n, tile[i]);
+    }
+}
 
 // One pipeline stage = 2*UNR token rows.  Addresses of out-of-range columns are clamped (their products only
 // reach accumulator rows/columns that are never written back), so column masks are not needed.  Rows past the
@@ -59,15 +100,12 @@ __device__ __forceinline__ void load_stage_impl(const IO *__restrict__ A, const 
 }
 template <typename IO>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
+    __shared__ float ctile[WT * WT];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // make everything derived from it scalar
-    const long long w = (long long)blockIdx.x * 4 + wave;
-    const int tile = (int)(w % p.tiles_pad), ks = (int)(w / p.tiles_pad);
-    if (tile >= p.tiles_m * p.tiles_n) return;  // padding waves (no barrier in this kernel)
-    const int tm = tile / p.tiles_n, tn = tile % p.tiles_n;
-    const int m0 = tm * WT, n0 = tn * WT;
-    const long long r0 = (long long)ks * p.slab;
-    const long long r1 = (r0 + p.slab < p.rows) ? r0 + p.slab : p.rows;
+    int m0, n0;
+    long long r0, r1;
+    tile_of_wave(p, wave, m0, n0, r0, r1);
     const IO *__restrict__ A = static_cast<const IO *>(p.A);
     const IO *__restrict__ B = static_cast<const IO *>(p.B);
     const int half = lane >> 5, l32 = lane & 31;
@@ -116,18 +154,133 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         SS2D_MFMA_STAGE(a0, b0)
     }
 #undef SS2D_MFMA_STAGE
-    // accumulator register e of a 32x32 tile: row = 8*(e/4) + 4*(lane/32) + e%4, column = lane%32
+    flush_tile(p, ctile, acc, m0, n0, lane, wave);
+}
+
+// ---- bf16 operands: v_mfma_f32_32x32x16_bf16.  The products of two bf16 values are exact in fp32, so this is
+// the same arithmetic as widening to fp32 (fp32 sums, another order) at 16x the MFMA rate: the fp32 form above is
+// MFMA-bound for bf16 inputs (64 cycles per 2 tokens per 32x32 block), this one is bound by its reads.
+// Operand layout (cdna_hip_programming.md, A/B operand lane maps): lane (r = lane & 31, h = lane >> 5) holds
+// k = 8h .. 8h+7 of row/column r, i.e. 8 consecutive tokens of one column: eight 2-byte reads at stride lda that
+// land in the halves of four registers (global_load_short_d16 / _d16_hi), each a 64-byte run per 32 lanes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int KG = 16;    // tokens per MFMA
+
+// Full group: token row r + j is workgroup-uniform, so a read is a scalar row base plus one of six loop-invariant
+// 32-bit lane offsets (aoff/boff = ((8h) * ld + column) * 2 bytes).  The 48 two-byte reads of a group land
+// zero-extended in 48 registers (`Raw`) and are packed into the 24 operand registers (`Frag`) once they have
+// arrived.  (global_load_short_d16 / _d16_hi would pack for free, but with SRAM ECC on they clear the other half
+// of the register instead of preserving it.)  One raw group is in flight per wave while the previous one's MFMAs
+// issue; two waves per SIMD (<= 256 registers with the 144 accumulators) keep ~100 KB per CU in flight.
+struct Raw { unsigned a[3][8], b[3][8]; };
+struct Frag { u32x4 a[3], b[3]; };
+
+__device__ __forceinline__ void load_group(const bf16 *__restrict__ A, const bf16 *__restrict__ B, const WgradParams &p,
+                                           long long r, const unsigned (&aoff)[3], const unsigned (&boff)[3], Raw &w) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const char *ra = reinterpret_cast<const char *>(A + (r + j) * p.lda);   // uniform: SGPR pair
+        const char *rb = reinterpret_cast<const char *>(B + (r + j) * p.ldb);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            w.a[i][j] = *reinterpret_cast<const unsigned short *>(ra + aoff[i]);
+            w.b[i][j] = *reinterpret_cast<const unsigned short *>(rb + boff[i]);
+        }
+    }
+}
+__device__ __forceinline__ void pack_group(const Raw &w, Frag &f) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int n = n0 + 32 * j + l32;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = m0 + 32 * i + 8 * (e >> 2) + 4 * half + (e & 3);
-                if (m < p.M && n < p.N) atomicAdd(p.C + (size_t)m * p.ldc + n, acc[i][j][e]);
-            }
+        for (int q = 0; q < 4; ++q) {
+            f.a[i][q] = w.a[i][2 * q] | (w.a[i][2 * q + 1] << 16);
+            f.b[i][q] = w.b[i][2 * q] | (w.b[i][2 * q + 1] << 16);
         }
+}
+
+// Ragged last group of a slab: rows past the end are clamped and zeroed with a bit mask.
+__device__ __forceinline__ void load_group_tail(const bf16 *__restrict__ A, const bf16 *__restrict__ B, const WgradParams &p,
+                                                long long r, long long r1, int h8, const int (&acol)[3], const int (&bcol)[3],
+                                                bf16x8 (&a)[3], bf16x8 (&b)[3]) {
+    u32x4 keep = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        long long row = r + h8 + j;
+        if (row >= r1) keep[j >> 1] &= (j & 1) ? 0x0000ffffu : 0xffff0000u;
+        row = row < r1 ? row : r1 - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            a[i][j] = A[row * p.lda + acol[i]];
+            b[i][j] = B[row * p.ldb + bcol[i]];
+        }
+    }
+    asm volatile("" : "+v"(keep));   // opaque: keeps the reads unconditional (see load_stage_impl)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[i] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, a[i]) & keep);
+        b[i] = __builtin_bit_cast(bf16x8, __builtin_bit_cast(u32x4, b[i]) & keep);
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void wgrad_bf16_kernel(const WgradParams p) {
+    __shared__ float ctile[WT * WT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int m0, n0;
+    long long r0, r1;
+    tile_of_wave(p, wave, m0, n0, r0, r1);
+    const bf16 *__restrict__ A = static_cast<const bf16 *>(p.A);
+    const bf16 *__restrict__ B = static_cast<const bf16 *>(p.B);
+    const int half = lane >> 5, l32 = lane & 31, h8 = 8 * half;
+    int acol[3], bcol[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        acol[i] = m0 + 32 * i + l32; acol[i] = acol[i] < p.M ? acol[i] : p.M - 1;
+        bcol[i] = n0 + 32 * i + l32; bcol[i] = bcol[i] < p.N ? bcol[i] : p.N - 1;
+    }
+    unsigned aoff[3], boff[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        aoff[i] = (unsigned)(h8 * p.lda + acol[i]) * 2u;
+        boff[i] = (unsigned)(h8 * p.ldb + bcol[i]) * 2u;
+    }
+    f16v acc[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+    const long long nfull = (r1 - r0) / KG;
+    if (nfull > 0) {   // every trip issues the same reads (the trip past the end re-reads the last group, unused)
+        const long long rlast = r0 + (nfull - 1) * KG;
+        Raw w;
+        Frag f;
+        load_group(A, B, p, r0, aoff, boff, w);
+        for (long long g = 0; g < nfull; ++g) {
+            pack_group(w, f);
+            const long long rn = r0 + (g + 1) * KG;
+            __builtin_amdgcn_sched_barrier(0);
+            load_group(A, B, p, rn < rlast ? rn : rlast, aoff, boff, w);
+            __builtin_amdgcn_sched_barrier(0);  // keep the reads ahead of the MFMAs they are meant to overlap
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (r0 + nfull * KG < r1) {  // ragged end of the slab: one masked group
+        bf16x8 a0[3], b0[3];
+        load_group_tail(A, B, p, r0 + nfull * KG, r1, h8, acol, bcol, a0, b0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0[i], b0[j], acc[i][j], 0, 0, 0);
+    }
+    flush_tile(p, ctile, acc, m0, n0, lane, wave);
 }
 
 }  // namespace
@@ -142,22 +295,23 @@ extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float 
     p.A = A; p.B = B; p.C = C; p.rows = rows; p.M = M; p.N = N; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_m = (M + WT - 1) / WT; p.tiles_n = (N + WT - 1) / WT;
     const int tiles = p.tiles_m * p.tiles_n;
-    p.tiles_pad = (tiles + 3) / 4 * 4;
-    // one wave per SIMD on every CU (1024 waves) when the token axis is long enough; a slab is at least 128 rows
+    // token slabs: 4 per workgroup (one per wave), about `target_waves` waves in all, at least 128 rows each.
+    // One wave per SIMD on every CU: the fp32 form cannot hold more (298 registers); the bf16 form could hold two
+    // (242), but twice the workgroups flush twice the atomics and measured 5-10 % slower.
     long long target_waves = 1024;
     if (const char *e = getenv("SS2D_WGRAD_WAVES")) { const long long v = atoll(e); if (v >= 4 && v <= 65536) target_waves = v; }  // tuning knob
-    long long ks = (target_waves + p.tiles_pad - 1) / p.tiles_pad;
+    long long ks = (target_waves + tiles - 1) / tiles;
     const long long max_ks = (rows + 127) / 128;
     if (ks > max_ks) ks = max_ks;
-    if (ks < 1) ks = 1;
+    ks = (ks + 3) / 4 * 4;
     long long slab = (rows + ks - 1) / ks;
     slab = (slab + 1) / 2 * 2;
-    ks = (rows + slab - 1) / slab;
     p.slab = slab; p.ksplit = (int)ks;
-    const long long nwg = ks * (p.tiles_pad / 4);
+    const long long nwg = (ks / 4) * tiles;
     if (nwg > 0x7fffffffLL) { ss2d_set_error("linear_wgrad: grid too large"); return -6; }
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SS2D_DTYPE_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    if (dtype == SS2D_DTYPE_BF16 && !getenv("SS2D_WGRAD_WIDEN")) hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);   // env: A/B against the fp32-MFMA form
+    else if (dtype == SS2D_DTYPE_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16>, dim3((unsigned)nwg), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, s, p);
     const int rc = (int)hipGetLastError();
     if (rc) ss2d_set_error("linear_wgrad: launch failed: %s", hipGetErrorString((hipError_t)rc));
