@@ -130,6 +130,19 @@ int ss2d_dwconv3x3_silu_bwd(int dtype, const void *x, const float *w, const floa
 int ss2d_dt_proj_fwd(int dtype, const void *x, const float *w, void *out, int batch, int ngroups, int D, int R, int L,
                      long long x_bg_stride, void *stream);
 
+/* Parameter transforms in front of the scan (mamba_sys.py:428-431; dt_projs_weight of :420), one launch each way:
+ *   A[g*Dm+d][n] = -exp(A_logs[k*Dm+d][n]),  D[g*Dm+d] = Ds[k*Dm+d],  bias[g*Dm+d] = dt_bias[k*Dm+d],
+ *   w[g][d][r] = dt_w[k][d][r],   all fp32, K direction groups of Dm channels, N states, rank R.
+ * regroup = 0: g = k (the reference's order).  regroup = 1 (K = 4): scan group g = 2*orientation + reversed takes the
+ * reference direction k = 2*reversed + orientation, the order ss2d_selective_scan_dir_* is used with.
+ * _bwd: gradients w.r.t. the outputs (scan-group order; any of dA/dD/dbias/dw may be null = zero) -> gradients
+ * w.r.t. the parameters (reference order), dA_logs = dA * A with A as produced by _fwd.  Outputs are overwritten. */
+int ss2d_scan_params_fwd(const float *A_logs, const float *Ds, const float *dt_bias, const float *dt_w, float *A,
+                         float *D, float *bias, float *w, int K, int Dm, int N, int R, int regroup, void *stream);
+int ss2d_scan_params_bwd(const float *A, const float *dA, const float *dD, const float *dbias, const float *dw,
+                         float *dA_logs, float *dDs, float *ddt_bias, float *ddt_w, int K, int Dm, int N, int R,
+                         int regroup, void *stream);
+
 /* Weight gradient of the bias-free in_proj / out_proj Linears (mamba_sys.py:298, :337; used :555, :562; the
  * reference gets it from autograd of nn.Linear): C[m][n] += sum_r A[r][m] * B[r][n] with A = dL/d(output)
  * (rows x M, row stride lda), B = the Linear's input (rows x N, row stride ldb), rows = batch*H*W tokens,

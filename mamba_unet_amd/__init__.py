@@ -6,7 +6,8 @@ code/networks/vision_mamba.py): `selective_scan_fn`, `SS2D`, `VSSBlock`, `VSSLay
 CPU path."""
 from .selective_scan_interface import SelectiveScanFn, scan_merge_fn, selective_scan_fn  # noqa: F401
 from .ss2d import SS2D, DropPath, VSSBlock, VSSLayer, VSSLayer_up  # noqa: F401
-from .ss2d_ops import cross_merge, cross_scan, dwconv3x3_silu, layer_norm, linear_nobias, linear_wgrad, outnorm_gate  # noqa: F401
+from .ss2d_ops import (cross_merge, cross_scan, dwconv3x3_silu, layer_norm, linear_nobias, linear_wgrad, outnorm_gate,  # noqa: F401
+                       scan_params)
 from .vssm import (VSSM, FinalPatchExpand_X4, MambaUnet, MambaUnetConfig, PatchEmbed2D,  # noqa: F401
                    PatchExpand, PatchMerging2D)
 

@@ -1,0 +1,79 @@
+// Parameter transforms in front of the selective scan, forward and backward, for gfx950
+// (/root/reference/code/networks/mamba_sys.py:428-431: As = -exp(A_logs.float()).view(K*D, N), Ds.view(K*D),
+// dt_projs_bias.view(K*D); the dt_projs_weight (K, D, R) of :420 rides along).
+// In the reference these are a handful of tiny elementwise ops per SS2D call, times their autograd twins; with the
+// fused-direction scan every one of them is followed by a regrouping copy (reference direction k = 2*rev +
+// orientation -> scan group 2*orientation + rev).  Here the lot is one launch each way: ~20 kernels of a few
+// hundred KB per block become 2.  `swap` regroups (k <-> g swaps the two index bits; an involution), 0 keeps k.
+#include "ss2d_common.h"
+#include "../../include/ss2d.h"
+
+namespace {
+
+struct ScanParamsArgs {
+    const float *a, *d, *b, *w;     // fwd: A_logs, Ds, dt_bias, dt_w        bwd: dA, dD, dbias, dw (scan-group order; nullable)
+    float *oa, *od, *ob, *ow;       // fwd: A, D, bias, w (scan-group order)  bwd: dA_logs, dDs, ddt_bias, ddt_w (reference order)
+    const float *A;                 // bwd: A = -exp(A_logs) as produced by fwd
+    int K, Dm, N, R, swap;
+};
+
+__device__ __forceinline__ int src_group(int g, int swap) { return swap ? (((g & 1) << 1) | (g >> 1)) : g; }
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void scan_params_kernel(const ScanParamsArgs p) {
+    const int per_row = p.N + 2 + p.R;                    // A row, D, bias, w row of one (group, channel)
+    const long long total = (long long)p.K * p.Dm * per_row;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int e = (int)(i % per_row);
+        const long long row = i / per_row;                // output row in fwd (scan-group order), input row in bwd
+        const int g = (int)(row / p.Dm), d = (int)(row % p.Dm);
+        const long long other = (long long)src_group(g, p.swap) * p.Dm + d;   // the row in reference order
+        if (e < p.N) {
+            if (!BWD) p.oa[row * p.N + e] = -expf(p.a[other * p.N + e]);
+            else p.oa[other * p.N + e] = p.a ? p.a[row * p.N + e] * p.A[row * p.N + e] : 0.0f;   // d(-exp x) = -exp x
+        } else if (e == p.N) {
+            if (!BWD) p.od[row] = p.d[other]; else p.od[other] = p.d ? p.d[row] : 0.0f;
+        } else if (e == p.N + 1) {
+            if (!BWD) p.ob[row] = p.b[other]; else p.ob[other] = p.b ? p.b[row] : 0.0f;
+        } else {
+            const int r = e - p.N - 2;
+            if (!BWD) p.ow[row * p.R + r] = p.w[other * p.R + r]; else p.ow[other * p.R + r] = p.w ? p.w[row * p.R + r] : 0.0f;
+        }
+    }
+}
+
+int run(bool bwd, ScanParamsArgs &p, void *stream, const char *name) {
+    if (p.K <= 0 || p.Dm <= 0 || p.N <= 0 || p.R <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
+    if (p.swap && p.K != 4) { ss2d_set_error("%s: regrouping needs K = 4 directions, got %d", name, p.K); return -4; }
+    const long long total = (long long)p.K * p.Dm * (p.N + 2 + p.R);
+    long long nwg = (total + 255) / 256;
+    if (nwg > 2048) nwg = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (bwd) hipLaunchKernelGGL(scan_params_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(scan_params_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    const int rc = (int)hipGetLastError();
+    if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int ss2d_scan_params_fwd(const float *A_logs, const float *Ds, const float *dt_bias, const float *dt_w,
+                                    float *A, float *D, float *bias, float *w, int K, int Dm, int N, int R,
+                                    int regroup, void *stream) {
+    if (!A_logs || !Ds || !dt_bias || !dt_w || !A || !D || !bias || !w) { ss2d_set_error("scan_params_fwd: null pointer"); return -2; }
+    ScanParamsArgs p{};
+    p.a = A_logs; p.d = Ds; p.b = dt_bias; p.w = dt_w; p.oa = A; p.od = D; p.ob = bias; p.ow = w;
+    p.K = K; p.Dm = Dm; p.N = N; p.R = R; p.swap = regroup != 0;
+    return run(false, p, stream, "scan_params_fwd");
+}
+
+extern "C" int ss2d_scan_params_bwd(const float *A, const float *dA, const float *dD, const float *dbias, const float *dw,
+                                    float *dA_logs, float *dDs, float *ddt_bias, float *ddt_w, int K, int Dm, int N,
+                                    int R, int regroup, void *stream) {
+    if (!A || !dA_logs || !dDs || !ddt_bias || !ddt_w) { ss2d_set_error("scan_params_bwd: null pointer"); return -2; }
+    ScanParamsArgs p{};
+    p.A = A; p.a = dA; p.d = dD; p.b = dbias; p.w = dw; p.oa = dA_logs; p.od = dDs; p.ob = ddt_bias; p.ow = ddt_w;
+    p.K = K; p.Dm = Dm; p.N = N; p.R = R; p.swap = regroup != 0;
+    return run(true, p, stream, "scan_params_bwd");
+}

@@ -20,7 +20,8 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import scan_merge_fn, selective_scan_fn
-from .ss2d_ops import apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate
+from .ss2d_ops import (apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate,
+                       scan_params)
 
 
 class DropPath(nn.Module):
@@ -136,19 +137,16 @@ class SS2D(nn.Module):
         L, N, R = H * W, self.d_state, self.dt_rank
         Cx = R + 2 * N
         # reference direction k = 2*rev + orientation  ->  scan group 2*orientation + rev: swap the two index bits
-        # (plain views + one small copy; no index tensor, so the step stays HIP-graph capturable)
-        def regroup(t):
-            return t.reshape(2, 2, *t.shape[1:]).transpose(0, 1).reshape(t.shape)
+        # (plain views / one fused kernel; no index tensor, so the step stays HIP-graph capturable)
         xs2 = dirs_scatter2(x)                                                                  # (B, 2, D, L)
         w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
         x_dbl = torch.matmul(w_cat.unsqueeze(0), xs2).view(B, 4, Cx, L)                         # group = 2*orientation + rev
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
-        dts = dt_proj(dts, regroup(self.dt_projs_weight))                                       # (B, 4, D, L)
+        A, Dv, bias, dt_w = scan_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight, regroup=True)
+        dts = dt_proj(dts, dt_w)                                                                # (B, 4, D, L)
         cast = (lambda t: t) if (self.bf16_scan_io and xs2.dtype == torch.bfloat16) else (lambda t: t.float())
-        A = regroup(-torch.exp(self.A_logs.float()).view(4, D, N)).reshape(4 * D, N)
         return scan_merge_fn(cast(xs2).reshape(B, 2 * D, L), cast(dts).reshape(B, 4 * D, L), A,
-                             cast(Bs), cast(Cs), regroup(self.Ds.float().view(4, D)).reshape(-1),
-                             regroup(self.dt_projs_bias.float()).reshape(-1), H, W)
+                             cast(Bs), cast(Cs), Dv, bias, H, W)
 
     def _scan_core(self, x: torch.Tensor):
         """forward_corev0 up to (not including) out_norm: x (B, D, H, W) -> merged y (B, H, W, D)."""

@@ -412,3 +412,54 @@ def dt_proj(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     if x.is_cuda and R in (6, 12) and L % 4 == 0 and x.stride(3) == 1 and x.stride(1) % 4 == 0 and x.data_ptr() % 16 == 0:
         return _DtProj.apply(x, weight)
     return torch.matmul(weight.unsqueeze(0), x)
+
+
+class _ScanParams(torch.autograd.Function):
+    """The parameter transforms in front of the scan (mamba_sys.py:428-431 and the dt_projs_weight of :420) in one
+    launch each way: A = -exp(A_logs), Ds, dt_projs_bias, dt_projs_weight, optionally regrouped from the reference's
+    direction order to the scan-group order of `scan_merge_fn` (csrc/ss2d_scanparams.hip)."""
+
+    @staticmethod
+    def forward(ctx, A_logs, Ds, dt_bias, dt_w, regroup):
+        _need_gpu(A_logs, "scan_params")
+        K, Dm, R = dt_w.shape
+        N = A_logs.shape[1]
+        if A_logs.shape[0] != K * Dm or Ds.numel() != K * Dm or dt_bias.numel() != K * Dm:
+            raise ValueError("scan_params: inconsistent parameter shapes")
+        src = [t.detach().float().contiguous() for t in (A_logs, Ds, dt_bias, dt_w)]
+        dev = A_logs.device
+        A = torch.empty((K * Dm, N), device=dev, dtype=torch.float32)
+        D = torch.empty((K * Dm,), device=dev, dtype=torch.float32)
+        bias = torch.empty((K * Dm,), device=dev, dtype=torch.float32)
+        w = torch.empty((K, Dm, R), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = _lib.load().ss2d_scan_params_fwd(*[_lib.ptr(t) for t in src], _lib.ptr(A), _lib.ptr(D), _lib.ptr(bias),
+                                                  _lib.ptr(w), K, Dm, N, R, int(regroup), _stream())
+        _lib.check(rc, "ss2d_scan_params_fwd")
+        ctx.save_for_backward(A)
+        ctx.meta = (K, Dm, N, R, int(regroup), A_logs.dtype, Ds.dtype, dt_bias.dtype, dt_w.dtype, tuple(dt_bias.shape))
+        return A, D, bias, w
+
+    @staticmethod
+    def backward(ctx, dA, dD, dbias, dw):
+        (A,) = ctx.saved_tensors
+        K, Dm, N, R, regroup, *dts, bias_shape = ctx.meta
+        g = [None if t is None else t.float().contiguous() for t in (dA, dD, dbias, dw)]
+        dev = A.device
+        dA_logs = torch.empty((K * Dm, N), device=dev, dtype=torch.float32)
+        dDs = torch.empty((K * Dm,), device=dev, dtype=torch.float32)
+        ddt_bias = torch.empty(bias_shape, device=dev, dtype=torch.float32)
+        ddt_w = torch.empty((K, Dm, R), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            rc = _lib.load().ss2d_scan_params_bwd(_lib.ptr(A), *[_lib.ptr(t) for t in g], _lib.ptr(dA_logs), _lib.ptr(dDs),
+                                                  _lib.ptr(ddt_bias), _lib.ptr(ddt_w), K, Dm, N, R, regroup, _stream())
+        _lib.check(rc, "ss2d_scan_params_bwd")
+        return dA_logs.to(dts[0]), dDs.to(dts[1]), ddt_bias.to(dts[2]), ddt_w.to(dts[3]), None
+
+
+def scan_params(A_logs: torch.Tensor, Ds: torch.Tensor, dt_projs_bias: torch.Tensor, dt_projs_weight: torch.Tensor,
+                regroup: bool = False):
+    """(A_logs (K*D, N), Ds (K*D), dt_projs_bias (K, D), dt_projs_weight (K, D, R)) ->
+    (A = -exp(A_logs) (K*D, N), D (K*D), delta_bias (K*D), dt weight (K, D, R)), fp32; with `regroup` in the
+    scan-group order (row-major, row-major reversed, column-major, column-major reversed) of `scan_merge_fn`."""
+    return _ScanParams.apply(A_logs, Ds, dt_projs_bias, dt_projs_weight, regroup)

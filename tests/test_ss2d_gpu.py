@@ -303,3 +303,28 @@ def test_dt_proj_kernel(B, G, D, R, L, dtype):
     assert rel_l2(out.detach().float().cpu(), ref.detach()) < tol
     assert rel_l2(xd.grad[:, :, :R].float().cpu(), xr.grad[:, :, :R]) < tol
     assert rel_l2(wd.grad.cpu(), wr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("Dm,N,R,regroup", [(192, 16, 6, True), (192, 16, 6, False), (24, 5, 3, True), (1536, 16, 48, True)])
+def test_scan_params_kernel(Dm, N, R, regroup):
+    """A = -exp(A_logs), Ds, dt_projs_bias, dt_projs_weight (mamba_sys.py:428-431, :420) in one launch each way,
+    optionally regrouped to the scan-group order (reference direction k = [0, 2, 1, 3][group]); fp32 tolerance."""
+    from mamba_unet_amd import scan_params
+    K = 4
+    gen = torch.Generator().manual_seed(Dm + N)
+    A_logs = torch.log(torch.rand(K * Dm, N, generator=gen) * 15 + 1)
+    Ds, bias, w = torch.randn(K * Dm, generator=gen), torch.randn(K, Dm, generator=gen), torch.randn(K, Dm, R, generator=gen)
+    grads = [torch.randn(K * Dm, N, generator=gen), torch.randn(K * Dm, generator=gen), torch.randn(K * Dm, generator=gen),
+             torch.randn(K, Dm, R, generator=gen)]
+    order = [0, 2, 1, 3] if regroup else [0, 1, 2, 3]
+    ref_in = [t.double().requires_grad_(True) for t in (A_logs, Ds, bias, w)]
+    ref_out = [(-torch.exp(ref_in[0])).view(K, Dm, N)[order].reshape(K * Dm, N), ref_in[1].view(K, Dm)[order].reshape(-1),
+               ref_in[2][order].reshape(-1), ref_in[3][order]]
+    torch.autograd.backward(ref_out, [g.double() for g in grads])
+    dev_in = [t.cuda().requires_grad_(True) for t in (A_logs, Ds, bias, w)]
+    dev_out = scan_params(*dev_in, regroup=regroup)
+    torch.autograd.backward(list(dev_out), [g.cuda() for g in grads])
+    for got, want in zip(dev_out, ref_out):
+        assert got.shape == want.shape and rel_l2(got.detach().cpu(), want.detach()) < 1e-6
+    for got, want in zip(dev_in, ref_in):
+        assert got.grad.shape == want.grad.shape and rel_l2(got.grad.cpu(), want.grad) < 1e-6
