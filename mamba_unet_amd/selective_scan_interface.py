@@ -132,12 +132,14 @@ class ScanMergeFn(torch.autograd.Function):
     """Direction-aware selective scan + CrossMerge in one autograd node (mamba_sys.py:436-449 without the flips):
     the scan groups are ordered (row-major, row-major reversed, column-major, column-major reversed); reversed groups
     walk the un-flipped tensors backwards in place (rev_mask), a direction and its reversal share one copy of u and,
-    in the backward, one copy of dout (u_groups = 2).  Returns the merged y (B, H, W, D)."""
+    in the backward, one copy of dout (u_groups = 2).  Returns the merged y (B, H, W, D).
+    With `x` (B, D, H, W), the image u2 was scattered from, the gradient w.r.t. u goes straight to x as one 4-slot
+    gather of the scan's du (instead of pair sum -> add to the x_proj gradient -> 2-slot gather), and u2 gets none."""
 
     REV_MASK, U_GROUPS = 0b1010, 2
 
     @staticmethod
-    def forward(ctx, u2, delta, A, Bm, Cm, D, delta_bias, H, W):
+    def forward(ctx, u2, delta, A, Bm, Cm, D, delta_bias, H, W, x=None):
         if not u2.is_cuda:
             raise RuntimeError("scan_merge_fn: GPU tensors required (no CPU path in mamba_unet_amd)")
         batch, dim, L = delta.shape
@@ -161,9 +163,12 @@ class ScanMergeFn(torch.autograd.Function):
             _lib.check(rc, "ss2d_selective_scan_dir_fwd")
             rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(out), _lib.ptr(y), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_gather")
+        if x is not None and tuple(x.shape) != (batch, Dch, H, W):
+            raise ValueError(f"scan_merge_fn: x {tuple(x.shape)} is not (batch, d, H, W) = {(batch, Dch, H, W)}")
         ctx.save_for_backward(u_, delta_, A_, B_, C_, D_, bias_, ckpt)
         ctx.meta = (code, H, W, u2.dtype, delta.dtype, A.dtype, Bm.dtype, Cm.dtype, None if D is None else D.dtype,
                     None if delta_bias is None else delta_bias.dtype)
+        ctx.x_dtype = None if x is None else x.dtype
         return y
 
     @staticmethod
@@ -189,14 +194,21 @@ class ScanMergeFn(torch.autograd.Function):
                                                  _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
                                                  ScanMergeFn.REV_MASK, _stream())
             _lib.check(rc, "ss2d_selective_scan_dir_bwd")
-        du2 = du.view(batch, 2, 2, Dch, L).sum(2).view(batch, 2 * Dch, L)   # a direction and its reversal share u
+            dx = None
+            if ctx.x_dtype is not None:   # all four directions' du -> dx in one pass (the adjoint of the scatter)
+                dx = torch.empty((batch, Dch, H, W), device=g.device, dtype=u.dtype)
+                rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(du), _lib.ptr(dx), batch, Dch, H, W, 0, _stream())
+                _lib.check(rc, "ss2d_dirs_gather")
         cast = lambda t, d: None if t is None else t.to(d)  # noqa: E731
+        du2 = None
+        if dx is None:
+            du2 = du.view(batch, 2, 2, Dch, L).sum(2).view(batch, 2 * Dch, L)   # a direction and its reversal share u
         return (cast(du2, dts[0]), cast(ddelta, dts[1]), cast(dA, dts[2]), cast(dB, dts[3]), cast(dC, dts[4]),
-                cast(dD, dts[5]), cast(dbias, dts[6]), None, None)
+                cast(dD, dts[5]), cast(dbias, dts[6]), None, None, cast(dx, ctx.x_dtype))
 
 
-def scan_merge_fn(u2, delta, A, B, C, D, delta_bias, H, W):
+def scan_merge_fn(u2, delta, A, B, C, D, delta_bias, H, W, x=None):
     """u2 (b, 2*d, l): row-major and column-major copies of x; delta (b, 4*d, l), A (4*d, n), B, C (b, 4, n, l), D,
     delta_bias (4*d) in scan-group order (row-major, row-major reversed, column-major, column-major reversed), all in
     un-reversed memory order.  softplus(delta + bias) as in SS2D.  Returns y (b, H, W, d) = CrossMerge of the scans."""
-    return ScanMergeFn.apply(u2, delta, A, B, C, D, delta_bias, H, W)
+    return ScanMergeFn.apply(u2, delta, A, B, C, D, delta_bias, H, W, x)

@@ -146,7 +146,7 @@ class SS2D(nn.Module):
         dts = dt_proj(dts, dt_w)                                                                # (B, 4, D, L)
         cast = (lambda t: t) if (self.bf16_scan_io and xs2.dtype == torch.bfloat16) else (lambda t: t.float())
         return scan_merge_fn(cast(xs2).reshape(B, 2 * D, L), cast(dts).reshape(B, 4 * D, L), A,
-                             cast(Bs), cast(Cs), Dv, bias, H, W)
+                             cast(Bs), cast(Cs), Dv, bias, H, W, x=x)
 
     def _scan_core(self, x: torch.Tensor):
         """forward_corev0 up to (not including) out_norm: x (B, D, H, W) -> merged y (B, H, W, D)."""
