@@ -76,3 +76,18 @@ def check(rc: int, what: str) -> None:
 def ptr(t):
     """Device pointer of a torch tensor (None -> NULL)."""
     return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def zeros_group(device, *shapes):
+    """fp32 zero tensors of the given shapes (None -> None) carved out of ONE zero-filled buffer: the accumulated
+    gradients of a backward (dA, dD, dbias ...) then cost one fill launch instead of one each.  Pieces start on
+    256-byte boundaries."""
+    import math
+    import torch
+    offs, total = [], 0
+    for sh in shapes:
+        offs.append(total)
+        if sh is not None:
+            total += (math.prod(sh) + 63) // 64 * 64
+    buf = torch.zeros((total,), device=device, dtype=torch.float32)
+    return [None if sh is None else buf[o:o + math.prod(sh)].view(sh) for sh, o in zip(shapes, offs)]

@@ -99,11 +99,9 @@ class SelectiveScanFn(torch.autograd.Function):
         dout = _prep(dout, "dout", u.dtype)
         lib = _lib.load()
         du, ddelta = torch.empty_like(u), torch.empty_like(u)
-        dA = torch.zeros_like(A)
-        dB, dC = torch.zeros_like(B, dtype=torch.float32), torch.zeros_like(C, dtype=torch.float32)
-        dD = torch.zeros_like(D) if D is not None else None
+        sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
+        dA, dD, dbias, dB, dC = _lib.zeros_group(u.device, sh(A), sh(D), sh(bias), sh(B), sh(C))   # one fill launch
         dz = torch.empty_like(z) if z is not None else None
-        dbias = torch.zeros_like(bias) if bias is not None else None
         with torch.cuda.device(u.device):
             rc = lib.ss2d_selective_scan_bwd(ctx.code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B), _lib.ptr(C),
                                              _lib.ptr(D), _lib.ptr(z), _lib.ptr(bias), _lib.ptr(dout), _lib.ptr(ckpt),
@@ -181,10 +179,8 @@ class ScanMergeFn(torch.autograd.Function):
         g = dy.to(u.dtype).contiguous()
         dys2 = torch.empty((batch, 2, Dch, L), device=g.device, dtype=u.dtype)
         du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
-        dA = torch.zeros_like(A)
-        dB, dC = torch.zeros_like(Bm, dtype=torch.float32), torch.zeros_like(Cm, dtype=torch.float32)
-        dD = torch.zeros_like(D) if D is not None else None
-        dbias = torch.zeros_like(bias) if bias is not None else None
+        sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
+        dA, dD, dbias, dB, dC = _lib.zeros_group(g.device, sh(A), sh(D), sh(bias), sh(Bm), sh(Cm))   # one fill launch
         with torch.cuda.device(g.device):
             rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_scatter")

@@ -120,8 +120,7 @@ class _DwConvSiLU(torch.autograd.Function):
         B, D, H, W, cl, ldx, in_dtype, w_dtype, b_dtype, code = ctx.meta
         g = dy.to(xf.dtype).contiguous()
         dx = torch.empty((B, H, W, D) if cl else (B, D, H, W), device=g.device, dtype=xf.dtype)
-        dw = torch.zeros_like(wf)
-        db = torch.zeros_like(bf) if bf is not None else None
+        dw, db = _lib.zeros_group(g.device, tuple(wf.shape), None if bf is None else tuple(bf.shape))
         with torch.cuda.device(g.device):
             rc = _lib.load().ss2d_dwconv3x3_silu_bwd(code, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(g),
                                                      _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), B, D, H, W, cl, ldx, D,
@@ -259,7 +258,7 @@ class _OutNormGate(torch.autograd.Function):
         g = g if g.is_contiguous() else g.contiguous()
         dy = torch.empty_like(y2)
         dz = torch.empty((rows, D), device=g.device, dtype=y2.dtype)
-        dg, db = torch.zeros_like(g32), torch.zeros_like(b32)
+        dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(b32.shape))
         with torch.cuda.device(g.device):
             rc = _lib.load().ss2d_outnorm_gate_bwd(code, _lib.ptr(g), _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32),
                                                    _lib.ptr(b32), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dy),
@@ -305,7 +304,7 @@ class _LayerNorm(torch.autograd.Function):
         g = dout.reshape(rows, D).to(odt)
         g = g if g.is_contiguous() else g.contiguous()
         dx = torch.empty_like(x2)
-        dg, db = torch.zeros_like(g32), torch.zeros_like(g32)
+        dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(g32.shape))
         with torch.cuda.device(g.device):
             rc = _lib.load().ss2d_layernorm_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
                                                 _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), rows, D, _stream())
