@@ -146,3 +146,37 @@ __device__ __forceinline__ f4 load4m(const IO *__restrict__ row, int pos, int L,
 
 // thread-local error string shared by the C-ABI entry points
 void ss2d_set_error(const char *fmt, ...);
+
+// Workgroup column sums for the dgamma / dbeta of the norm kernels: every lane holds K four-element partial sums of
+// two quantities for column chunk (lane % LW) + LW*k.  Half-waves that share columns (LW = 32) are folded with a
+// lane exchange, every wave stores its partials in its own LDS slot, and after one barrier the threads add the NWV
+// slots of a column and send ONE global atomic per column and workgroup.  (LDS float atomics instead of the slots
+// cost 7 us per launch at 1024 threads.)  red: NWV * 2 * K * 256 floats.
+template <int K, int NWV, int LW>
+__device__ __forceinline__ void wg_colsum2(float *red, f4 (&a)[K], f4 (&b)[K], int D, float *out_a, float *out_b) {
+    const int lane64 = threadIdx.x & 63, wave = threadIdx.x >> 6, nchunk = D >> 2;
+    if (LW == 32) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[k][e] += __shfl_xor(a[k][e], 32, 64); b[k][e] += __shfl_xor(b[k][e], 32, 64); }
+    }
+    if (lane64 < LW) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane64 + LW * k;
+            if (c < nchunk) {
+                *reinterpret_cast<f4 *>(red + (wave * 2 + 0) * K * 256 + 4 * c) = a[k];
+                *reinterpret_cast<f4 *>(red + (wave * 2 + 1) * K * 256 + 4 * c) = b[k];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += NWV * 64) {
+        const int which = i >= D, col = which ? i - D : i;
+        float s = 0.0f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) s += red[(w * 2 + which) * K * 256 + col];
+        atomicAdd((which ? out_b : out_a) + col, s);
+    }
+}

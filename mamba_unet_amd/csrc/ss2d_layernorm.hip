@@ -79,13 +79,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LNParams p) {
 
 template <int K, int NWV, int LW, typename TI, typename TO>
 __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
-    __shared__ float red[2][K * 256];
+    __shared__ __attribute__((aligned(16))) float red[NWV * 2 * K * 256];
     constexpr int RPW = 64 / LW;
     const int lane = threadIdx.x & (LW - 1);
     const long long wave0 = ((long long)blockIdx.x * NWV + (threadIdx.x >> 6)) * RPW + ((threadIdx.x & 63) / LW);
     const long long nwaves = (long long)gridDim.x * NWV * RPW;
-    for (int i = threadIdx.x; i < 2 * K * 256; i += NWV * 64) (&red[0][0])[i] = 0.0f;
-    __syncthreads();
     const int D = p.D, nchunk = D >> 2;
     const TI *__restrict__ X = static_cast<const TI *>(p.x);
     const TO *__restrict__ G = static_cast<const TO *>(p.dout);
@@ -126,22 +124,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
             if (c < nchunk) st4(DX + r * D + 4 * c, (dn[k] - m1 - nh[k] * m2) * rstd);
         }
     }
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int c = lane + LW * k;
-        if (c < nchunk) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(&red[0][4 * c + e], ag[k][e]);
-                atomicAdd(&red[1][4 * c + e], ab[k][e]);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < D; i += NWV * 64) {
-        atomicAdd(p.dgamma + i, red[0][i]);
-        atomicAdd(p.dbeta + i, red[1][i]);
-    }
+    wg_colsum2<K, NWV, LW>(red, ag, ab, D, p.dgamma, p.dbeta);
 }
 
 template <typename TI, typename TO>

@@ -87,11 +87,9 @@ __global__ __launch_bounds__(256) void normgate_fwd_kernel(const NormGateParams 
 
 template <int K, int NWV, typename IO>
 __global__ __launch_bounds__(NWV * 64) void normgate_bwd_kernel(const NormGateParams p) {
-    __shared__ float red[2][K * 256];   // workgroup sums of dgamma / dbeta
+    __shared__ __attribute__((aligned(16))) float red[NWV * 2 * K * 256];   // per-wave partial sums of dgamma / dbeta
     const int lane = threadIdx.x & 63;
     const long long wave0 = (long long)blockIdx.x * NWV + (threadIdx.x >> 6), nwaves = (long long)gridDim.x * NWV;
-    for (int i = threadIdx.x; i < 2 * K * 256; i += NWV * 64) (&red[0][0])[i] = 0.0f;
-    __syncthreads();
     const int D = p.D, nchunk = D >> 2;
     const IO *__restrict__ Y = static_cast<const IO *>(p.y);
     const IO *__restrict__ Z = static_cast<const IO *>(p.z);
@@ -150,24 +148,9 @@ __global__ __launch_bounds__(NWV * 64) void normgate_bwd_kernel(const NormGatePa
             }
         }
     }
-    // per-lane column sums -> workgroup sums in LDS -> one global atomic per column and workgroup (at most 256
-    // workgroups: thousands of same-address global atomics would serialise in L2)
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int c = lane + 64 * k;
-        if (c < nchunk) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(&red[0][4 * c + e], ag[k][e]);
-                atomicAdd(&red[1][4 * c + e], ab[k][e]);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < D; i += NWV * 64) {
-        atomicAdd(p.dgamma + i, red[0][i]);
-        atomicAdd(p.dbeta + i, red[1][i]);
-    }
+    // per-lane column sums -> per-wave LDS slots -> one global atomic per column and workgroup (at most 256
+    // workgroups: thousands of same-address global atomics would serialise at the memory side)
+    wg_colsum2<K, NWV, 64>(red, ag, ab, D, p.dgamma, p.dbeta);
 }
 
 int check(const NormGateParams &p, int dtype, const char *name) {
