@@ -71,17 +71,22 @@ int ss2d_selective_scan_bwd(int dtype, const void *u, const void *delta, const f
  *              scan group g uses group g / (ngroups / u_groups).  With the four SS2D directions ordered
  *              (row-major, row-major reversed, column-major, column-major reversed), u_groups = 2 lets a direction
  *              and its reversal share one copy of the input.  du is still written per scan group (batch, dim, L).
- * ss2d_selective_scan_fwd/_bwd are these with u_groups = ngroups, rev_mask = 0.  ngroups <= 32 when rev_mask != 0. */
+ *   bc_bg_stride : elements between consecutive (batch, group) blocks of B and of C; 0 = dense (dstate * L).  Lets
+ *              the scan read B / C in place from the x_proj output x_dbl (batch, K, R + 2N, L) of mamba_sys.py:407-417
+ *              (B = x_dbl + R*L, C = x_dbl + (R+N)*L, stride (R + 2N) * L) instead of from contiguous copies.
+ *              dB / dC stay dense.
+ * ss2d_selective_scan_fwd/_bwd are these with u_groups = ngroups, rev_mask = 0, dense B / C.
+ * ngroups <= 32 when rev_mask != 0. */
 int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
                                 const void *C, const float *D, const void *z, const float *delta_bias, void *out,
                                 float *last_state, float *ckpt, int batch, int dim, int L, int dstate, int ngroups,
-                                int delta_softplus, int u_groups, unsigned rev_mask, void *stream);
+                                int delta_softplus, int u_groups, unsigned rev_mask, long long bc_bg_stride, void *stream);
 int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
                                 const void *C, const float *D, const void *z, const float *delta_bias,
                                 const void *dout, const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
                                 float *dC, float *dD, void *dz, float *ddelta_bias, int batch, int dim, int L,
                                 int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask,
-                                void *stream);
+                                long long bc_bg_stride, void *stream);
 
 /* CrossScan (mamba_sys.py:403-404): x (B, D, H, W) -> xs (B, 4, D, H*W); _bwd is its adjoint
  * (sums the four directions back into dx). */

@@ -32,6 +32,7 @@ struct ScanBwdParams {
     int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg, rounds, cb;
     int Gu;              // u and dout have Gu groups per batch; scan group g uses group g / (G / Gu)
     unsigned rev_mask;   // bit g: group g runs over its rows in reverse memory order
+    long long bc_stride; // elements between consecutive (batch, group) blocks of B and of C (N*L when dense); dB/dC are dense
 };
 
 #define SS2D_FSTEP(n)                                                                  \
@@ -110,8 +111,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
     const int L = p.L, N = p.N;
     const bool rev = DIRS && ((p.rev_mask >> g) & 1u);
     const int ug = DIRS ? g / (p.G / p.Gu) : g;
-    const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * N * (size_t)L;
-    const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * N * (size_t)L;
+    const size_t bcs = DIRS ? (size_t)p.bc_stride : N * (size_t)L;   // the plain path keeps its dense addressing
+    const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * bcs;
+    const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * bcs;
     float *__restrict__ dBg = p.dB + (size_t)(b * p.G + g) * N * (size_t)L;
     float *__restrict__ dCg = p.dC + (size_t)(b * p.G + g) * N * (size_t)L;
 
@@ -413,7 +415,7 @@ extern "C" int ss2d_selective_scan_bwd(int dtype, const void *u, const void *del
                                        float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
                                        int dim, int L, int dstate, int ngroups, int delta_softplus, void *stream) {
     return ss2d_selective_scan_dir_bwd(dtype, u, delta, A, B, C, D, z, delta_bias, dout, ckpt, du, ddelta, dA, dB, dC, dD,
-                                       dz, ddelta_bias, batch, dim, L, dstate, ngroups, delta_softplus, ngroups, 0u, stream);
+                                       dz, ddelta_bias, batch, dim, L, dstate, ngroups, delta_softplus, ngroups, 0u, 0, stream);
 }
 
 extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
@@ -421,7 +423,7 @@ extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void 
                                            const void *dout, const float *ckpt, void *du, void *ddelta, float *dA,
                                            float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
                                            int dim, int L, int dstate, int ngroups, int delta_softplus, int u_groups,
-                                           unsigned rev_mask, void *stream) {
+                                           unsigned rev_mask, long long bc_bg_stride, void *stream) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_bwd: unknown dtype %d", dtype); return -1; }
     if (!u || !delta || !A || !B || !C || !dout || !ckpt || !du || !ddelta || !dA || !dB || !dC) {
         ss2d_set_error("selective_scan_bwd: null required pointer"); return -2; }
@@ -431,8 +433,11 @@ extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void 
     if (dim % ngroups) { ss2d_set_error("selective_scan_bwd: dim %d not divisible by ngroups %d", dim, ngroups); return -5; }
     if (u_groups <= 0 || ngroups % u_groups) { ss2d_set_error("selective_scan_bwd: u_groups %d must divide ngroups %d", u_groups, ngroups); return -5; }
     if (ngroups > 32 && rev_mask) { ss2d_set_error("selective_scan_bwd: rev_mask needs ngroups <= 32"); return -5; }
+    const long long bc_dense = (long long)dstate * L;
+    if (bc_bg_stride == 0) bc_bg_stride = bc_dense;
+    if (bc_bg_stride < bc_dense) { ss2d_set_error("selective_scan_bwd: bc_bg_stride %lld < dstate*L", bc_bg_stride); return -5; }
     ScanBwdParams p;
-    p.Gu = u_groups; p.rev_mask = rev_mask;
+    p.Gu = u_groups; p.rev_mask = rev_mask; p.bc_stride = bc_bg_stride;
     p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
     p.D = D; p.z = z; p.bias = delta_bias; p.dout = dout; p.ckpt = ckpt;
     p.du = du; p.ddelta = ddelta; p.dA = dA; p.dB = dB; p.dC = dC; p.dD = D ? dD : nullptr;
@@ -461,10 +466,11 @@ extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void 
     const size_t lds = 2 * NP * 4 * 16 * sizeof(f4) + (size_t)nw * ACC_WAVE_FLOATS * sizeof(float) +
                        (size_t)nw * rounds * NP * 4 * sizeof(f2) + (size_t)nw * rounds * (64 + 8) * sizeof(float);
     const uintptr_t amask = dtype == SS2D_DTYPE_BF16 ? 7 : 15;  // 4 elements
-    const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dout |
-                                         (uintptr_t)du | (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & amask) == 0);
+    const bool vec4 = (L % 4 == 0) && (bc_bg_stride % 4 == 0) &&
+                      ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)dout | (uintptr_t)du |
+                         (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
-    const bool dirs = rev_mask != 0 || u_groups != ngroups;
+    const bool dirs = rev_mask != 0 || u_groups != ngroups || bc_bg_stride != bc_dense;
     int rc = dtype == SS2D_DTYPE_BF16
                  ? (dirs ? launch_bwd_nw<bf16, true>(nw, p, z != nullptr, vec4, lds, s) : launch_bwd_nw<bf16, false>(nw, p, z != nullptr, vec4, lds, s))
                  : (dirs ? launch_bwd_nw<float, true>(nw, p, z != nullptr, vec4, lds, s) : launch_bwd_nw<float, false>(nw, p, z != nullptr, vec4, lds, s));

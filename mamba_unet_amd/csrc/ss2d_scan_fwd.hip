@@ -32,6 +32,7 @@ struct ScanFwdParams {
     int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg;
     int Gu;              // u has Gu groups per batch; scan group g reads u group g / (G / Gu)
     unsigned rev_mask;   // bit g: group g runs over its rows in reverse memory order
+    long long bc_stride; // elements between consecutive (batch, group) blocks of B and of C (N*L when dense)
 };
 
 // Inclusive scan of (a, h) over the 16 lanes of each DPP row, two independent states interleaved so
@@ -74,8 +75,9 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     const IO *__restrict__ drow = static_cast<const IO *>(p.delta) + rowoff;
     const IO *__restrict__ zrow = HAS_Z ? static_cast<const IO *>(p.z) + rowoff : nullptr;
     IO *__restrict__ orow = static_cast<IO *>(p.out) + rowoff;
-    const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * N * (size_t)L;
-    const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * N * (size_t)L;
+    const size_t bcs = DIRS ? (size_t)p.bc_stride : N * (size_t)L;   // the plain path keeps its dense addressing
+    const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * bcs;
+    const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * bcs;
 
     f2 A2[NP], carry[NP];
 #pragma unroll
@@ -261,14 +263,14 @@ extern "C" int ss2d_selective_scan_fwd(int dtype, const void *u, const void *del
                                        void *out, float *last_state, float *ckpt, int batch, int dim, int L,
                                        int dstate, int ngroups, int delta_softplus, void *stream) {
     return ss2d_selective_scan_dir_fwd(dtype, u, delta, A, B, C, D, z, delta_bias, out, last_state, ckpt, batch, dim, L,
-                                       dstate, ngroups, delta_softplus, ngroups, 0u, stream);
+                                       dstate, ngroups, delta_softplus, ngroups, 0u, 0, stream);
 }
 
 extern "C" int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
                                            const void *C, const float *D, const void *z, const float *delta_bias,
                                            void *out, float *last_state, float *ckpt, int batch, int dim, int L,
                                            int dstate, int ngroups, int delta_softplus, int u_groups,
-                                           unsigned rev_mask, void *stream) {
+                                           unsigned rev_mask, long long bc_bg_stride, void *stream) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_fwd: unknown dtype %d", dtype); return -1; }
     if (!u || !delta || !A || !B || !C || !out) { ss2d_set_error("selective_scan_fwd: null required pointer"); return -2; }
     if (batch <= 0 || dim <= 0 || L <= 0 || dstate <= 0 || ngroups <= 0) { ss2d_set_error("selective_scan_fwd: non-positive size"); return -3; }
@@ -276,8 +278,11 @@ extern "C" int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void 
     if (dim % ngroups) { ss2d_set_error("selective_scan_fwd: dim %d not divisible by ngroups %d", dim, ngroups); return -5; }
     if (u_groups <= 0 || ngroups % u_groups) { ss2d_set_error("selective_scan_fwd: u_groups %d must divide ngroups %d", u_groups, ngroups); return -5; }
     if (ngroups > 32 && rev_mask) { ss2d_set_error("selective_scan_fwd: rev_mask needs ngroups <= 32"); return -5; }
+    const long long bc_dense = (long long)dstate * L;
+    if (bc_bg_stride == 0) bc_bg_stride = bc_dense;
+    if (bc_bg_stride < bc_dense) { ss2d_set_error("selective_scan_fwd: bc_bg_stride %lld < dstate*L", bc_bg_stride); return -5; }
     ScanFwdParams p;
-    p.Gu = u_groups; p.rev_mask = rev_mask;
+    p.Gu = u_groups; p.rev_mask = rev_mask; p.bc_stride = bc_bg_stride;
     p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
     p.D = D; p.z = z; p.bias = delta_bias; p.out = out; p.last = last_state; p.ckpt = ckpt;
     p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
@@ -289,10 +294,10 @@ extern "C" int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void 
     if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_fwd: grid too large"); return -6; }
     p.nwg = (int)nwg;
     const uintptr_t amask = dtype == SS2D_DTYPE_BF16 ? 7 : 15;  // 4 elements
-    const bool vec4 = (L % 4 == 0) && ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)out |
-                                         (uintptr_t)z) & amask) == 0);
+    const bool vec4 = (L % 4 == 0) && (bc_bg_stride % 4 == 0) &&
+                      ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)out | (uintptr_t)z) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
-    const bool dirs = rev_mask != 0 || u_groups != ngroups;
+    const bool dirs = rev_mask != 0 || u_groups != ngroups || bc_bg_stride != bc_dense;
     int rc = dtype == SS2D_DTYPE_BF16
                  ? (dirs ? launch_fwd_nw<bf16, true>(nw, p, z != nullptr, vec4, s) : launch_fwd_nw<bf16, false>(nw, p, z != nullptr, vec4, s))
                  : (dirs ? launch_fwd_nw<float, true>(nw, p, z != nullptr, vec4, s) : launch_fwd_nw<float, false>(nw, p, z != nullptr, vec4, s));

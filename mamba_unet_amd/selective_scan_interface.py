@@ -146,7 +146,15 @@ class ScanMergeFn(torch.autograd.Function):
             raise ValueError(f"scan_merge_fn: inconsistent shapes u {tuple(u2.shape)} delta {tuple(delta.shape)} B {tuple(Bm.shape)}")
         io = torch.bfloat16 if u2.dtype == torch.bfloat16 else torch.float32
         code = _BF16 if io == torch.bfloat16 else _F32
-        u_, delta_, B_, C_ = _prep(u2, "u", io), _prep(delta, "delta", io), _prep(Bm, "B", io), _prep(Cm, "C", io)
+        u_, delta_ = _prep(u2, "u", io), _prep(delta, "delta", io)
+        # B and C may be two row ranges of every block of one x_proj output (torch.split views): read in place
+        bcs = Bm.stride(1)
+        in_place = (Bm.dtype == io and Cm.dtype == io and Bm.stride() == Cm.stride() and Bm.stride(3) == 1
+                    and Bm.stride(2) == L and Bm.stride(0) == 4 * bcs and bcs >= N * L and bcs % 4 == 0)
+        if in_place:
+            B_, C_ = Bm, Cm
+        else:
+            B_, C_, bcs = _prep(Bm, "B", io), _prep(Cm, "C", io), N * L
         A_, D_, bias_ = _prep(A, "A"), _prep(D, "D"), _prep(delta_bias, "delta_bias")
         needs_grad = any(t is not None and t.requires_grad for t in (u2, delta, A, Bm, Cm, D, delta_bias))
         lib = _lib.load()
@@ -157,7 +165,7 @@ class ScanMergeFn(torch.autograd.Function):
         with torch.cuda.device(u_.device):
             rc = lib.ss2d_selective_scan_dir_fwd(code, _lib.ptr(u_), _lib.ptr(delta_), _lib.ptr(A_), _lib.ptr(B_), _lib.ptr(C_),
                                                  _lib.ptr(D_), None, _lib.ptr(bias_), _lib.ptr(out), None, _lib.ptr(ckpt),
-                                                 batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, _stream())
+                                                 batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, bcs, _stream())
             _lib.check(rc, "ss2d_selective_scan_dir_fwd")
             rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(out), _lib.ptr(y), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_gather")
@@ -167,6 +175,7 @@ class ScanMergeFn(torch.autograd.Function):
         ctx.meta = (code, H, W, u2.dtype, delta.dtype, A.dtype, Bm.dtype, Cm.dtype, None if D is None else D.dtype,
                     None if delta_bias is None else delta_bias.dtype)
         ctx.x_dtype = None if x is None else x.dtype
+        ctx.bcs = bcs
         return y
 
     @staticmethod
@@ -188,7 +197,7 @@ class ScanMergeFn(torch.autograd.Function):
                                                  _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
                                                  _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
                                                  _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
-                                                 ScanMergeFn.REV_MASK, _stream())
+                                                 ScanMergeFn.REV_MASK, ctx.bcs, _stream())
             _lib.check(rc, "ss2d_selective_scan_dir_bwd")
             dx = None
             if ctx.x_dtype is not None:   # all four directions' du -> dx in one pass (the adjoint of the scatter)

@@ -91,7 +91,36 @@ def test_dir_entry_points_reject_bad_grouping():
     t = torch.zeros(64, device="cuda")
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     rc = lib.ss2d_selective_scan_dir_fwd(0, P(t), P(t), P(t), P(t), P(t), None, None, None, P(t), None, None,
-                                         1, 4, 4, 1, 4, 1, 3, 0, st)        # u_groups 3 does not divide 4 groups
+                                         1, 4, 4, 1, 4, 1, 3, 0, 0, st)     # u_groups 3 does not divide 4 groups
     assert rc < 0 and b"u_groups" in lib.ss2d_last_error()
     rc = lib.ss2d_dirs_gather(0, 9, P(t), P(t), 1, 1, 2, 2, 0, st)
     assert rc < 0 and b"layout" in lib.ss2d_last_error()
+
+
+@pytest.mark.parametrize("B,D,H,W,N,R,dtype", [(2, 32, 28, 28, 16, 6, torch.float32), (1, 8, 5, 8, 16, 4, torch.float32),
+                                               (2, 32, 28, 28, 16, 12, torch.bfloat16)])
+def test_scan_merge_fn_reads_b_c_in_place(B, D, H, W, N, R, dtype):
+    """B and C handed over as the torch.split views of one x_proj output (bc_bg_stride = (R+2N)*L) give bit for bit
+    what contiguous copies give, forward and every gradient (same kernel arithmetic, other addresses)."""
+    from mamba_unet_amd import scan_merge_fn
+    L = H * W
+    gen = torch.Generator().manual_seed(L + R)
+    r = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    x_dbl = r(B, 4, R + 2 * N, L).cuda().to(dtype)
+    xs2, delta = r(B, 2 * D, L).cuda().to(dtype), (r(B, 4 * D, L) * 0.5).cuda().to(dtype)
+    A, Dv, bias = -torch.exp(r(4 * D, N) * 0.5).cuda(), torch.rand(4 * D, generator=gen).cuda() + 0.5, (r(4 * D) * 0.2 - 2.0).cuda()
+    gy = r(B, H, W, D).cuda().to(dtype)
+    res = []
+    for in_place in (True, False):
+        xd = x_dbl.clone().requires_grad_(True)
+        _, Bs, Cs = torch.split(xd, [R, N, N], dim=2)
+        if not in_place:
+            Bs, Cs = Bs.contiguous(), Cs.contiguous()
+        leaves = [t.clone().requires_grad_(True) for t in (xs2, delta, A, Dv, bias)]
+        y = scan_merge_fn(leaves[0], leaves[1], leaves[2], Bs, Cs, leaves[3], leaves[4], H, W)
+        y.backward(gy)
+        res.append([y.detach(), xd.grad] + [t.grad for t in leaves])
+    for a, b in zip(*res):
+        # dA / dD / dbias / dB / dC are sums of float atomics: order-dependent in the last bits
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5)
+    assert torch.equal(res[0][0], res[1][0])           # the forward is deterministic
