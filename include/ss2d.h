@@ -148,6 +148,12 @@ int ss2d_scan_params_bwd(const float *A, const float *dA, const float *dD, const
                          float *dA_logs, float *dDs, float *ddt_bias, float *ddt_w, int K, int Dm, int N, int R,
                          int regroup, void *stream);
 
+/* Gradient of the x_proj output x_dbl (batch, K, R + 2N, L) (mamba_sys.py:407-417; the autograd of its `torch.split`)
+ * assembled in one pass: rows [0, R) of every (batch, k) block from d_dts (nblocks, R, L) in `dtype`, rows [R, R+N) and
+ * [R+N, R+2N) from the scan backward's fp32 dB / dC (nblocks, N, L), cast to `dtype`.  nblocks = batch * K. */
+int ss2d_xdbl_grad_pack(int dtype, const void *d_dts, const float *dB, const float *dC, void *out, long long nblocks,
+                        int R, int N, int L, void *stream);
+
 /* Weight gradient of the bias-free in_proj / out_proj Linears (mamba_sys.py:298, :337; used :555, :562; the
  * reference gets it from autograd of nn.Linear): C[m][n] += sum_r A[r][m] * B[r][n] with A = dL/d(output)
  * (rows x M, row stride lda), B = the Linear's input (rows x N, row stride ldb), rows = batch*H*W tokens,

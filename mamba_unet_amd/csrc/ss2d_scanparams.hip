@@ -77,3 +77,67 @@ extern "C" int ss2d_scan_params_bwd(const float *A, const float *dA, const float
     p.K = K; p.Dm = Dm; p.N = N; p.R = R; p.swap = regroup != 0;
     return run(true, p, stream, "scan_params_bwd");
 }
+
+// ---- gradient of the x_proj output, assembled in one pass (mamba_sys.py:417, the autograd of `torch.split`):
+//     out[blk][c][l] = c < R ? d_dts[blk][c][l] : c < R+N ? dB[blk][c-R][l] : dC[blk][c-R-N][l]
+// d_dts in the activations' storage type, dB / dC the scan backward's fp32 accumulators: the two fp32 -> bf16 cast
+// passes and the concatenation of the eager graph are this one kernel (4 elements per lane).
+namespace {
+
+struct PackArgs {
+    const void *d_dts;
+    const float *dB, *dC;
+    void *out;
+    long long nblocks;
+    int R, N, L;
+};
+
+template <typename IO, int E>
+__global__ __launch_bounds__(256) void xdbl_grad_pack_kernel(const PackArgs p) {
+    const int Cx = p.R + 2 * p.N, lq = p.L / E;                     // E-element groups per row
+    const long long total = p.nblocks * Cx * lq;
+    const IO *__restrict__ dts = static_cast<const IO *>(p.d_dts);
+    IO *__restrict__ out = static_cast<IO *>(p.out);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int l = (int)(i % lq) * E;
+        const long long row = i / lq;
+        const int c = (int)(row % Cx);
+        const long long blk = row / Cx;
+        IO *o = out + row * p.L + l;
+        if (E == 4) {
+            f4 v;
+            if (c < p.R) v = ld4(dts + (blk * p.R + c) * p.L + l);
+            else if (c < p.R + p.N) v = ld4(p.dB + (blk * p.N + c - p.R) * p.L + l);
+            else v = ld4(p.dC + (blk * p.N + c - p.R - p.N) * p.L + l);
+            st4(o, v);
+        } else {
+            float v;
+            if (c < p.R) v = ld1(dts + (blk * p.R + c) * p.L + l);
+            else if (c < p.R + p.N) v = p.dB[(blk * p.N + c - p.R) * p.L + l];
+            else v = p.dC[(blk * p.N + c - p.R - p.N) * p.L + l];
+            st1(o, v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ss2d_xdbl_grad_pack(int dtype, const void *d_dts, const float *dB, const float *dC, void *out,
+                                   long long nblocks, int R, int N, int L, void *stream) {
+    if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("xdbl_grad_pack: unknown dtype %d", dtype); return -1; }
+    if (!d_dts || !dB || !dC || !out) { ss2d_set_error("xdbl_grad_pack: null pointer"); return -2; }
+    if (nblocks <= 0 || R <= 0 || N <= 0 || L <= 0) { ss2d_set_error("xdbl_grad_pack: non-positive size"); return -3; }
+    PackArgs p{d_dts, dB, dC, out, nblocks, R, N, L};
+    const bool h = dtype == SS2D_DTYPE_BF16;
+    const uintptr_t amask = h ? 7 : 15;
+    const bool vec = L % 4 == 0 && ((((uintptr_t)d_dts | (uintptr_t)out) & amask) == 0) && ((((uintptr_t)dB | (uintptr_t)dC) & 15) == 0);
+    const long long total = nblocks * (R + 2 * N) * (vec ? L / 4 : L);
+    long long nwg = (total + 255) / 256;
+    if (nwg > 16384) nwg = 16384;
+    hipStream_t s = (hipStream_t)stream;
+    if (vec) { if (h) hipLaunchKernelGGL((xdbl_grad_pack_kernel<bf16, 4>), dim3((unsigned)nwg), dim3(256), 0, s, p); else hipLaunchKernelGGL((xdbl_grad_pack_kernel<float, 4>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
+    else     { if (h) hipLaunchKernelGGL((xdbl_grad_pack_kernel<bf16, 1>), dim3((unsigned)nwg), dim3(256), 0, s, p); else hipLaunchKernelGGL((xdbl_grad_pack_kernel<float, 1>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
+    const int rc = (int)hipGetLastError();
+    if (rc) ss2d_set_error("xdbl_grad_pack: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}

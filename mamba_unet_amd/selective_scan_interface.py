@@ -217,3 +217,110 @@ def scan_merge_fn(u2, delta, A, B, C, D, delta_bias, H, W, x=None):
     delta_bias (4*d) in scan-group order (row-major, row-major reversed, column-major, column-major reversed), all in
     un-reversed memory order.  softplus(delta + bias) as in SS2D.  Returns y (b, H, W, d) = CrossMerge of the scans."""
     return ScanMergeFn.apply(u2, delta, A, B, C, D, delta_bias, H, W, x)
+
+
+class ScanCoreFn(torch.autograd.Function):
+    """dt_proj + direction-aware selective scan + CrossMerge on the x_proj output, one autograd node
+    (mamba_sys.py:417-449 without the split copies, casts and flips): x_dbl (b, 4, R+2N, l) in scan-group order is read
+    in place three times -- rows [0, R) by the dt_proj kernel, rows [R, R+N) / [R+N, R+2N) as B / C by the scan
+    (bc_bg_stride) -- and its gradient is assembled in one pass from d_dts and the scan backward's fp32 dB / dC
+    (ss2d_xdbl_grad_pack) instead of two cast passes and a concatenation.  Arguments as `scan_merge_fn`, with
+    dt_w (4, d, R) in place of delta."""
+
+    @staticmethod
+    def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None):
+        if not x_dbl.is_cuda:
+            raise RuntimeError("scan_core_fn: GPU tensors required (no CPU path in mamba_unet_amd)")
+        batch, K, Cx, L = x_dbl.shape
+        Dch, R, N = dt_w.shape[1], dt_w.shape[2], A.shape[1]
+        dim = 4 * Dch
+        if K != 4 or Cx != R + 2 * N or L != H * W or u2.shape != (batch, 2 * Dch, L) or dt_w.shape[0] != 4 or A.shape[0] != dim:
+            raise ValueError(f"scan_core_fn: inconsistent shapes u {tuple(u2.shape)} x_dbl {tuple(x_dbl.shape)} dt_w {tuple(dt_w.shape)}")
+        if x is not None and tuple(x.shape) != (batch, Dch, H, W):
+            raise ValueError(f"scan_core_fn: x {tuple(x.shape)} is not (batch, d, H, W) = {(batch, Dch, H, W)}")
+        io = torch.bfloat16 if x_dbl.dtype == torch.bfloat16 else torch.float32
+        code = _BF16 if io == torch.bfloat16 else _F32
+        u_, xd, w32 = _prep(u2, "u", io), _prep(x_dbl, "x_dbl", io), _prep(dt_w, "dt_w")
+        A_, D_, bias_ = _prep(A, "A"), _prep(D, "D"), _prep(delta_bias, "delta_bias")
+        needs_grad = any(t is not None and t.requires_grad for t in (u2, x_dbl, dt_w, A, D, delta_bias, x))
+        lib = _lib.load()
+        dev = xd.device
+        out = torch.empty((batch, dim, L), device=dev, dtype=io)
+        ckpt = torch.empty((batch, dim, lib.ss2d_scan_num_chunks(L), N), device=dev, dtype=torch.float32) if needs_grad else None
+        y = torch.empty((batch, H, W, Dch), device=dev, dtype=io)
+        with torch.cuda.device(dev):
+            if R in (6, 12) and L % 4 == 0:
+                delta = torch.empty((batch, dim, L), device=dev, dtype=io)
+                rc = lib.ss2d_dt_proj_fwd(code, _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(delta), batch, 4, Dch, R, L, Cx * L, _stream())
+                _lib.check(rc, "ss2d_dt_proj_fwd")
+            else:   # other ranks: library GEMM
+                with torch.autocast("cuda", enabled=False):
+                    delta = torch.matmul(w32.to(io).unsqueeze(0), xd[:, :, :R]).reshape(batch, dim, L)
+            if (Cx * L) % 4 == 0:
+                B_, C_, bcs = xd[:, :, R:R + N], xd[:, :, R + N:], Cx * L
+            else:
+                B_, C_, bcs = xd[:, :, R:R + N].contiguous(), xd[:, :, R + N:].contiguous(), N * L
+            rc = lib.ss2d_selective_scan_dir_fwd(code, _lib.ptr(u_), _lib.ptr(delta), _lib.ptr(A_), _lib.ptr(B_), _lib.ptr(C_),
+                                                 _lib.ptr(D_), None, _lib.ptr(bias_), _lib.ptr(out), None, _lib.ptr(ckpt),
+                                                 batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, bcs, _stream())
+            _lib.check(rc, "ss2d_selective_scan_dir_fwd")
+            rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(out), _lib.ptr(y), batch, Dch, H, W, 1, _stream())
+            _lib.check(rc, "ss2d_dirs_gather")
+        ctx.save_for_backward(u_, delta, A_, xd, w32, D_, bias_, ckpt)
+        ctx.meta = (code, H, W, R, u2.dtype, x_dbl.dtype, dt_w.dtype, A.dtype, None if D is None else D.dtype,
+                    None if delta_bias is None else delta_bias.dtype, None if x is None else x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, delta, A, xd, w32, D, bias, ckpt = ctx.saved_tensors
+        code, H, W, R, u_dt, xdbl_dt, w_dt, A_dt, D_dt, b_dt, x_dt = ctx.meta
+        batch, dim, L = delta.shape
+        N, Dch, Cx = A.shape[1], dim // 4, xd.shape[2]
+        io = xd.dtype
+        lib = _lib.load()
+        g = dy.to(io).contiguous()
+        dev = g.device
+        dys2 = torch.empty((batch, 2, Dch, L), device=dev, dtype=io)
+        du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
+        sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
+        dA, dD, dbias, dB, dC = _lib.zeros_group(dev, sh(A), sh(D), sh(bias), (batch, 4, N, L), (batch, 4, N, L))
+        if (Cx * L) % 4 == 0:
+            B_, C_, bcs = xd[:, :, R:R + N], xd[:, :, R + N:], Cx * L
+        else:
+            B_, C_, bcs = xd[:, :, R:R + N].contiguous(), xd[:, :, R + N:].contiguous(), N * L
+        d_xdbl = torch.empty_like(xd)
+        with torch.cuda.device(dev):
+            rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
+            _lib.check(rc, "ss2d_dirs_scatter")
+            rc = lib.ss2d_selective_scan_dir_bwd(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B_), _lib.ptr(C_),
+                                                 _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
+                                                 _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
+                                                 _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
+                                                 ScanMergeFn.REV_MASK, bcs, _stream())
+            _lib.check(rc, "ss2d_selective_scan_dir_bwd")
+            dx = du2 = None
+            if x_dt is not None:      # all four directions' du -> dx in one pass (the adjoint of the scatter)
+                dx = torch.empty((batch, Dch, H, W), device=dev, dtype=io)
+                rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(du), _lib.ptr(dx), batch, Dch, H, W, 0, _stream())
+                _lib.check(rc, "ss2d_dirs_gather")
+            else:
+                du2 = du.view(batch, 2, 2, Dch, L).sum(2).view(batch, 2 * Dch, L)
+            # dt_proj backward on library GEMMs (K = d contraction for d_dts, K = l for the weight)
+            with torch.autocast("cuda", enabled=False):
+                dd4 = ddelta.view(batch, 4, Dch, L)
+                d_dts = torch.matmul(w32.to(io).transpose(1, 2).unsqueeze(0), dd4).contiguous()          # (b, 4, R, l)
+                d_w = torch.matmul(dd4, xd[:, :, :R].transpose(2, 3)).sum(0, dtype=torch.float32)         # (4, d, R)
+            rc = lib.ss2d_xdbl_grad_pack(code, _lib.ptr(d_dts), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(d_xdbl), batch * 4, R, N, L, _stream())
+            _lib.check(rc, "ss2d_xdbl_grad_pack")
+        cast = lambda t, d: None if t is None else t.to(d)  # noqa: E731
+        return (cast(du2, u_dt), cast(d_xdbl, xdbl_dt), cast(d_w, w_dt), cast(dA, A_dt), cast(dD, D_dt), cast(dbias, b_dt),
+                None, None, cast(dx, x_dt))
+
+
+def scan_core_fn(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None):
+    """u2 (b, 2*d, l): row-major and column-major copies of x; x_dbl (b, 4, R+2N, l): the x_proj output with rows
+    [dts | B | C] per scan group; dt_w (4, d, R); A (4*d, n), D, delta_bias (4*d) -- all in scan-group order
+    (row-major, row-major reversed, column-major, column-major reversed).  delta = dt_w @ dts, softplus(delta + bias)
+    as in SS2D.  Returns y (b, H, W, d) = CrossMerge of the four scans."""
+    return ScanCoreFn.apply(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x)

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from .selective_scan_interface import scan_merge_fn, selective_scan_fn
+from .selective_scan_interface import scan_core_fn, scan_merge_fn, selective_scan_fn
 from .ss2d_ops import (apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate,
                        scan_params)
 
@@ -141,12 +141,15 @@ class SS2D(nn.Module):
         xs2 = dirs_scatter2(x)                                                                  # (B, 2, D, L)
         w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
         x_dbl = torch.matmul(w_cat.unsqueeze(0), xs2).view(B, 4, Cx, L)                         # group = 2*orientation + rev
-        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         A, Dv, bias, dt_w = scan_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight, regroup=True)
+        if xs2.dtype == torch.float32 or (self.bf16_scan_io and xs2.dtype == torch.bfloat16):
+            # dt_proj + scan + merge as one node reading x_dbl in place (rows [dts | B | C] of every block)
+            return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x)
+        # the reference's fp32 casts around the scan (:423-426) under autocast
+        dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = dt_proj(dts, dt_w)                                                                # (B, 4, D, L)
-        cast = (lambda t: t) if (self.bf16_scan_io and xs2.dtype == torch.bfloat16) else (lambda t: t.float())
-        return scan_merge_fn(cast(xs2).reshape(B, 2 * D, L), cast(dts).reshape(B, 4 * D, L), A,
-                             cast(Bs), cast(Cs), Dv, bias, H, W, x=x)
+        return scan_merge_fn(xs2.float().reshape(B, 2 * D, L), dts.float().reshape(B, 4 * D, L), A,
+                             Bs.float(), Cs.float(), Dv, bias, H, W, x=x)
 
     def _scan_core(self, x: torch.Tensor):
         """forward_corev0 up to (not including) out_norm: x (B, D, H, W) -> merged y (B, H, W, D)."""

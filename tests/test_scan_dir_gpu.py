@@ -124,3 +124,44 @@ def test_scan_merge_fn_reads_b_c_in_place(B, D, H, W, N, R, dtype):
         # dA / dD / dbias / dB / dC are sums of float atomics: order-dependent in the last bits
         assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5)
     assert torch.equal(res[0][0], res[1][0])           # the forward is deterministic
+
+
+@pytest.mark.parametrize("B,D,H,W,N,R,dtype", [(2, 32, 28, 28, 16, 6, torch.float32), (1, 8, 5, 7, 16, 3, torch.float32),
+                                               (1, 24, 8, 12, 16, 12, torch.float32), (2, 32, 28, 28, 16, 12, torch.bfloat16)])
+def test_scan_core_fn_matches_composition(B, D, H, W, N, R, dtype):
+    """scan_core_fn (dt_proj + scan + merge on x_dbl in place, packed x_dbl gradient) against the same function
+    composed from torch.split, an fp64 einsum for dt_proj and the fp64 oracle pipeline."""
+    from mamba_unet_amd import scan_core_fn
+    L = H * W
+    gen = torch.Generator().manual_seed(L * 7 + R)
+    r = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    q = (lambda t: t.to(dtype).float()) if dtype == torch.bfloat16 else (lambda t: t)
+    x = q(r(B, D, H, W))
+    x_dbl = q(torch.cat([r(B, 4, R, L) * 0.5, r(B, 4, 2 * N, L)], 2))
+    dt_w = r(4, D, R) * 0.3
+    A, Dv, bias = -torch.exp(r(4 * D, N) * 0.5), torch.rand(4 * D, generator=gen) + 0.5, r(4 * D) * 0.2 - 2.0
+    gy = q(r(B, H, W, D))
+    # oracle composition (fp64)
+    ref = [t.clone().double().requires_grad_(True) for t in (x, x_dbl, dt_w, A, Dv, bias)]
+    xs2 = torch.stack([ref[0].reshape(B, D, L), ref[0].transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
+    dts, Bs, Cs = torch.split(ref[1], [R, N, N], dim=2)
+    delta = torch.einsum("bgrl,gdr->bgdl", dts, ref[2]).reshape(B, 4 * D, L)
+    if dtype == torch.bfloat16:
+        delta = delta.detach().to(dtype).double() + (delta - delta.detach())   # the kernel stores delta in bf16 (straight-through)
+    yr = _oracle(xs2, delta, ref[3], Bs, Cs, ref[4], ref[5], H, W)
+    yr.backward(gy.double())
+    act = (0, 1)
+    dev = [(t.cuda().to(dtype) if i in act else t.cuda()).requires_grad_(True) for i, t in enumerate((x, x_dbl, dt_w, A, Dv, bias))]
+    xs2d = torch.stack([dev[0].reshape(B, D, L), dev[0].transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
+    y = scan_core_fn(xs2d.detach(), dev[1], dev[2], dev[3], dev[4], dev[5], H, W, x=dev[0])
+    assert y.dtype == dtype and y.shape == (B, H, W, D)
+    y.backward(gy.cuda().to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(y.detach().float().cpu(), yr.detach()) < tol
+    names = ("x", "x_dbl", "dt_w", "A", "D", "bias")
+    for i, (d, rf) in enumerate(zip(dev, ref)):
+        # x only gets the u-path gradient here (xs2 was detached): compare with the oracle's d/dx through u
+        # dt_w's gradient is a GEMM over the bf16 ddelta / dts tensors: activation tolerance; A, D, bias are fp32 sums
+        t = tol if (i in act or names[i] == "dt_w") else (1e-5 if dtype == torch.float32 else 2e-3)
+        err = rel_l2(d.grad.float().cpu(), rf.grad)
+        assert err < t, (names[i], err)
