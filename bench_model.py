@@ -39,7 +39,9 @@ def main():
                     help="bf16: autocast + bf16 kernel I/O; bf16-fp32scan: autocast with the reference's fp32 casts around the scan")
     ap.add_argument("--literal-directions", action="store_true",
                     help="A/B: run cross_scan / scan / cross_merge literally (4 materialised directions) instead of the fused-direction path")
-    ap.add_argument("--graph", action="store_true", help="train mode, 1 GPU: capture the whole step in a HIP graph")
+    ap.add_argument("--graph", action="store_true",
+                    help="train mode, 1 GPU: capture the whole step in a HIP graph (experimental: refused unless "
+                         "SS2D_ALLOW_HIP_GRAPH=1, torch's reductions replay wrongly on this stack; not a number of record)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -117,6 +119,8 @@ def main():
     finite = bool(torch.isfinite(last.float()).all())
 
     if rank == 0:
+        if not finite:
+            print("bench_model.py: WARNING: the last step's output is not finite -- this run is not a valid measurement", file=sys.stderr)
         print(json.dumps({
             "metric": f"MambaUNet {args.mode} slices/s @{args.size}x{args.size}",
             "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "slices/s", "n_gpus": world,
@@ -128,7 +132,7 @@ def main():
                                    f"{args.batch} per GPU, {args.size}x{args.size}, {args.classes} classes",
                        "parallelism": f"DDP x{world} (batch-sharded slices, RCCL gradient all-reduce)"},
             "hip_graph": bool(args.graph and world == 1 and args.mode == "train"),
-            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "finite": finite}))
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "finite": finite, "valid": finite}))
     if dist is not None:
         dist.destroy_process_group()
 

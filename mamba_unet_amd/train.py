@@ -112,11 +112,23 @@ def supervised_step(model, optimizer, images, labels, n_classes, it, max_it, bas
 
 class GraphedSupervisedStep:
     """The whole supervised iteration (forward, loss, backward, SGD update) captured once in a HIP graph and
-    replayed: the step has ~2000 kernel launches and is launch-bound on the host at batch 24, a replay costs one
-    launch.  Single process / single GPU (DDP's bucketed all-reduce is not captured here).  Inputs are copied into
-    static buffers; the learning rate must be a device tensor (make_sgd(..., tensor_lr_device=dev))."""
+    replayed (one launch per step instead of ~1150).  Single process / single GPU (DDP's bucketed all-reduce is not
+    captured here).  Inputs are copied into static buffers; the learning rate must be a device tensor
+    (make_sgd(..., tensor_lr_device=dev)).
+
+    NOT USABLE on the ROCm 7.0 / PyTorch 2.10 stack of this image, and refused unless SS2D_ALLOW_HIP_GRAPH=1: from
+    the second replay on, torch's multi-block reduction kernels (`x.sum((0, 2, 3))` of the Dice statistics, the row
+    sums of bias gradients) return wrong sums -- the first of several reductions in a graph is right, the later
+    ones are not (scratch/graph_dice.py isolates it: no kernel of this package involved; every op of this package
+    replays bit-exactly, scratch/graph_ops.py).  The training loss then drifts and goes NaN within ~6 replays.
+    The eager step is GPU-bound since the fusions (26.8 ms eager vs 26.7 ms replayed), so nothing is lost."""
 
     def __init__(self, model, optimizer, images, labels, n_classes, max_it, base_lr=0.01, autocast_bf16=False, warmup=3):
+        import os
+        if not os.environ.get("SS2D_ALLOW_HIP_GRAPH"):
+            raise RuntimeError("GraphedSupervisedStep: HIP-graph replay of torch's reduction kernels returns wrong sums on "
+                               "this ROCm/PyTorch stack (see the class docstring); use supervised_step, or set "
+                               "SS2D_ALLOW_HIP_GRAPH=1 to experiment")
         self.opt, self.max_it, self.base_lr = optimizer, max_it, base_lr
         self.images, self.labels = images.clone(), labels.clone()
         args = (model, optimizer, self.images, self.labels, n_classes)
