@@ -11,7 +11,11 @@ from conftest import GOLDEN, rel_l2, rel_max
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,D,H,W", [(2, 3, 3, 5), (1, 40, 7, 7), (2, 33, 17, 20), (1, 192, 56, 56), (1, 8, 128, 128)])
+@pytest.mark.parametrize("B,D,H,W", [(2, 3, 3, 5), (1, 40, 7, 7), (2, 33, 17, 20), (1, 192, 56, 56), (1, 8, 128, 128),
+                                     (2, 130, 7, 7),      # small-image tile (128 x 8 x 8), two channel tiles, scalar path
+                                     (1, 132, 8, 8),      # small-image tile, vector path
+                                     (2, 36, 9, 8),       # just above the small-image limit: 16 x 16 tile with padding
+                                     (3, 64, 14, 14)])    # stage-2 shape
 def test_cross_scan_and_merge_bit_exact(B, D, H, W):
     from mamba_unet_amd import cross_merge, cross_scan
     from oracle.ss2d_ref import cross_merge_ref, cross_scan_ref
@@ -58,9 +62,17 @@ def test_cross_ops_gradients_are_adjoints():
 
 
 @pytest.mark.parametrize("B,D,H,W,cl", [(2, 5, 4, 6, True), (1, 40, 9, 33, True), (2, 64, 14, 14, False),
-                                        (1, 192, 56, 56, True)])
-def test_dwconv_silu_fwd_bwd(B, D, H, W, cl):
+                                        (1, 192, 56, 56, True),
+                                        (24, 40, 7, 7, True),      # narrow variant (W <= 16), several units per workgroup
+                                        (3, 33, 17, 16, True),     # narrow variant, ragged channels and rows
+                                        (2, 24, 20, 40, False)])   # wide variant, (B, D, H, W) input
+@pytest.mark.parametrize("reps", [None, "3"])
+def test_dwconv_silu_fwd_bwd(B, D, H, W, cl, reps, monkeypatch):
+    """reps: force 3 (image, row-tile) units per backward workgroup (SS2D_DWCONV_REPS), so the multi-unit walk with its
+    ragged last group runs on small shapes too (the default picks > 1 only from ~770 tiles up)."""
     from mamba_unet_amd import dwconv3x3_silu
+    if reps is not None:
+        monkeypatch.setenv("SS2D_DWCONV_REPS", reps)
     from oracle.ss2d_ref import dwconv3x3_silu_ref
     g = torch.Generator().manual_seed(D)
     wide = torch.randn(B, H, W, 2 * D, generator=g)            # emulates xz; the kernel reads its first half in place
