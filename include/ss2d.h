@@ -184,6 +184,17 @@ int ss2d_layernorm_bwd(int in_dtype, int out_dtype, const void *dout, const void
                        const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta, long long rows,
                        int D, void *stream);
 
+/* The same LayerNorm over the rows of a ps x ps pixel un-shuffle of x: x (batch, H, W, ps*ps*D) as the expand Linear
+ * of PatchExpand / FinalPatchExpand_X4 leaves it (mamba_sys.py:233-265), out / dout (batch, H*ps, W*ps, D) =
+ * norm(rearrange(x, 'b h w (p1 p2 c) -> b (h p1) (w p2) c')) (:244, :262); mean / rstd per output row; dx in the
+ * layout of x.  The rearranging copy becomes address arithmetic inside the kernel. */
+int ss2d_layernorm_unshuffle_fwd(int in_dtype, int out_dtype, const void *x, const float *gamma, const float *beta,
+                                 void *out, float *mean, float *rstd, long long batch, int H, int W, int ps, int D,
+                                 float eps, void *stream);
+int ss2d_layernorm_unshuffle_bwd(int in_dtype, int out_dtype, const void *dout, const void *x, const float *gamma,
+                                 const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta,
+                                 long long batch, int H, int W, int ps, int D, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,7 +20,23 @@ struct LNParams {
     long long rows;
     int D;
     float eps;
+    int ps, psH, psW;   // ps > 0: rows are gathered through a ps x ps pixel un-shuffle of x (B, psH, psW, ps*ps*D)
 };
+
+// Element offset in x (and dx) of normalised row r.  Plain: r * D.  Un-shuffle (the einops pattern
+// 'b h w (p1 p2 c) -> b (h p1) (w p2) c' of mamba_sys.py:244, :262): output row (b, h*ps + p1, w*ps + p2) is the
+// c-long run ((((b*H + h)*W + w)*ps + p1)*ps + p2) * c of the expand Linear's output -- the rearranging copy (231 MB
+// each way in front of the last LayerNorm) becomes address arithmetic.
+__device__ __forceinline__ long long ln_row_off(const LNParams &p, long long r) {
+    if (p.ps == 0) return r * p.D;
+    const int W4 = p.psW * p.ps, H4 = p.psH * p.ps;
+    const int w4 = (int)(r % W4);
+    const long long t = r / W4;
+    const int h4 = (int)(t % H4);
+    const long long b = t / H4;
+    const int h = h4 / p.ps, p1 = h4 % p.ps, w = w4 / p.ps, p2 = w4 % p.ps;
+    return ((((b * p.psH + h) * p.psW + w) * p.ps + p1) * p.ps + p2) * (long long)p.D;
+}
 
 // sum over the LW (64 or 32) lanes that share a row
 template <int LW>
@@ -51,10 +67,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LNParams p) {
     for (long long r = wave0; r < p.rows; r += nwaves) {
         f4 xv[K];
         float s = 0.0f;
+        const long long xoff = ln_row_off(p, r);
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + LW * k;
-            xv[k] = c < nchunk ? ld4(X + r * D + 4 * c) : f4{0, 0, 0, 0};
+            xv[k] = c < nchunk ? ld4(X + xoff + 4 * c) : f4{0, 0, 0, 0};
             s += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
         }
         const float mu = wave_sum_ln<LW>(s) * invD;
@@ -99,6 +116,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
     const float invD = 1.0f / (float)D;
     for (long long r = wave0; r < p.rows; r += nwaves) {
         const float mu = p.mean_in[r], rstd = p.rstd_in[r];
+        const long long xoff = ln_row_off(p, r);
         f4 nh[K], dn[K];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -108,7 +126,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
             dn[k] = f4{0, 0, 0, 0};
             if (c < nchunk) {
                 const f4 gv = ld4(G + r * D + 4 * c);
-                nh[k] = (ld4(X + r * D + 4 * c) - mu) * rstd;
+                nh[k] = (ld4(X + xoff + 4 * c) - mu) * rstd;
                 dn[k] = gv * g[k];
                 ag[k] += gv * nh[k];
                 ab[k] += gv;
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + LW * k;
-            if (c < nchunk) st4(DX + r * D + 4 * c, (dn[k] - m1 - nh[k] * m2) * rstd);
+            if (c < nchunk) st4(DX + xoff + 4 * c, (dn[k] - m1 - nh[k] * m2) * rstd);
         }
     }
     wg_colsum2<K, NWV, LW>(red, ag, ab, D, p.dgamma, p.dbeta);
@@ -197,4 +215,33 @@ extern "C" int ss2d_layernorm_bwd(int in_dtype, int out_dtype, const void *dout,
     p.dout = dout; p.x = x; p.gamma = gamma; p.mean_in = mean; p.rstd_in = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
     p.rows = rows; p.D = D;
     return dispatch(true, in_dtype, out_dtype, p, stream, "layernorm_bwd");
+}
+
+// LayerNorm over the rows of a ps x ps pixel un-shuffle of x (PatchExpand / FinalPatchExpand_X4, mamba_sys.py:233-265)
+static int check_ps(long long batch, int H, int W, int ps, const char *name) {
+    if (batch <= 0 || H <= 0 || W <= 0 || ps <= 0 || ps > 8) { ss2d_set_error("%s: bad un-shuffle geometry (batch %lld, H %d, W %d, ps %d)", name, batch, H, W, ps); return -3; }
+    return 0;
+}
+
+extern "C" int ss2d_layernorm_unshuffle_fwd(int in_dtype, int out_dtype, const void *x, const float *gamma, const float *beta,
+                                            void *out, float *mean, float *rstd, long long batch, int H, int W, int ps,
+                                            int D, float eps, void *stream) {
+    if (!x || !gamma || !beta || !out) { ss2d_set_error("layernorm_unshuffle_fwd: null pointer"); return -2; }
+    if ((mean == nullptr) != (rstd == nullptr)) { ss2d_set_error("layernorm_unshuffle_fwd: mean and rstd go together"); return -2; }
+    if (int rc = check_ps(batch, H, W, ps, "layernorm_unshuffle_fwd")) return rc;
+    LNParams p{};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.out = out; p.mean = mean; p.rstd = rstd; p.D = D; p.eps = eps;
+    p.rows = batch * H * ps * W * ps; p.ps = ps; p.psH = H; p.psW = W;
+    return dispatch(false, in_dtype, out_dtype, p, stream, "layernorm_unshuffle_fwd");
+}
+
+extern "C" int ss2d_layernorm_unshuffle_bwd(int in_dtype, int out_dtype, const void *dout, const void *x, const float *gamma,
+                                            const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta,
+                                            long long batch, int H, int W, int ps, int D, void *stream) {
+    if (!dout || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) { ss2d_set_error("layernorm_unshuffle_bwd: null pointer"); return -2; }
+    if (int rc = check_ps(batch, H, W, ps, "layernorm_unshuffle_bwd")) return rc;
+    LNParams p{};
+    p.dout = dout; p.x = x; p.gamma = gamma; p.mean_in = mean; p.rstd_in = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.D = D; p.rows = batch * H * ps * W * ps; p.ps = ps; p.psH = H; p.psW = W;
+    return dispatch(true, in_dtype, out_dtype, p, stream, "layernorm_unshuffle_bwd");
 }

@@ -274,42 +274,63 @@ def outnorm_gate(y: torch.Tensor, z: torch.Tensor, weight: torch.Tensor, bias: t
 
 
 class _LayerNorm(torch.autograd.Function):
+    """LayerNorm over the last axis; with ps > 0 over the rows of a ps x ps pixel un-shuffle of x (B, H, W, ps*ps*D):
+    out (B, H*ps, W*ps, D) = norm(rearrange(x, 'b h w (p1 p2 c) -> b (h p1) (w p2) c')), gathered inside the kernel."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, ps=0):
         _need_gpu(x, "layer_norm")
-        D = x.shape[-1]
         io, code = _io(x)
-        x2 = x.to(io).reshape(-1, D)
-        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        if ps:
+            B, H, W, C = x.shape
+            D = C // (ps * ps)
+            x2 = x.to(io)
+            x2 = x2 if x2.is_contiguous() else x2.contiguous()
+            out_shape, rows = (B, H * ps, W * ps, D), B * H * ps * W * ps
+        else:
+            D = x.shape[-1]
+            x2 = x.to(io).reshape(-1, D)
+            x2 = x2 if x2.is_contiguous() else x2.contiguous()
+            out_shape, rows = x.shape, x2.shape[0]
         # under bf16 autocast the consumer is a bf16 GEMM: write bf16 directly (torch would return fp32 and cast)
         out_bf16 = io == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
         ocode, odt = (_BF16, torch.bfloat16) if out_bf16 else (_F32, torch.float32)
-        rows = x2.shape[0]
         g32, b32 = weight.float().contiguous(), bias.float().contiguous()
         out = torch.empty((rows, D), device=x.device, dtype=odt)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        lib = _lib.load()
         with torch.cuda.device(x.device):
-            rc = _lib.load().ss2d_layernorm_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(out),
-                                                _lib.ptr(mean), _lib.ptr(rstd), rows, D, float(eps), _stream())
+            if ps:
+                rc = lib.ss2d_layernorm_unshuffle_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(out),
+                                                      _lib.ptr(mean), _lib.ptr(rstd), B, H, W, ps, D, float(eps), _stream())
+            else:
+                rc = lib.ss2d_layernorm_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(out),
+                                            _lib.ptr(mean), _lib.ptr(rstd), rows, D, float(eps), _stream())
         _lib.check(rc, "ss2d_layernorm_fwd")
         ctx.save_for_backward(x2, g32, mean, rstd)
-        ctx.meta = (code, ocode, odt, rows, D, x.shape, x.dtype, weight.dtype, bias.dtype)
-        return out.view(x.shape)
+        ctx.meta = (code, ocode, odt, rows, D, x.shape, x.dtype, weight.dtype, bias.dtype, ps)
+        return out.view(out_shape)
 
     @staticmethod
     def backward(ctx, dout):
         x2, g32, mean, rstd = ctx.saved_tensors
-        code, ocode, odt, rows, D, xshape, xdt, wdt, bdt = ctx.meta
+        code, ocode, odt, rows, D, xshape, xdt, wdt, bdt, ps = ctx.meta
         g = dout.reshape(rows, D).to(odt)
         g = g if g.is_contiguous() else g.contiguous()
         dx = torch.empty_like(x2)
         dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(g32.shape))
+        lib = _lib.load()
         with torch.cuda.device(g.device):
-            rc = _lib.load().ss2d_layernorm_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
-                                                _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), rows, D, _stream())
+            if ps:
+                B, H, W, _ = xshape
+                rc = lib.ss2d_layernorm_unshuffle_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
+                                                      _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), B, H, W, ps, D, _stream())
+            else:
+                rc = lib.ss2d_layernorm_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
+                                            _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), rows, D, _stream())
         _lib.check(rc, "ss2d_layernorm_bwd")
-        return dx.view(xshape).to(xdt), dg.to(wdt), db.to(bdt), None
+        return dx.view(xshape).to(xdt), dg.to(wdt), db.to(bdt), None, None
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -337,6 +358,24 @@ def apply_norm(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
             and module.bias is not None and x.is_cuda:
         return layer_norm(x, module.weight, module.bias, module.eps)
     return module(x)
+
+
+def pixel_unshuffle_cl(x: torch.Tensor, p: int) -> torch.Tensor:
+    """(B, H, W, p*p*c) -> (B, H*p, W*p, c), channel groups ordered (p1, p2, c) -- the einops pattern
+    'b h w (p1 p2 c) -> b (h p1) (w p2) c' of mamba_sys.py:244, :262 (a copy)."""
+    B, H, W, C = x.shape
+    c = C // (p * p)
+    return x.view(B, H, W, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(B, H * p, W * p, c)
+
+
+def apply_norm_unshuffle(module: torch.nn.Module, x: torch.Tensor, p: int) -> torch.Tensor:
+    """module(pixel_unshuffle_cl(x, p)) for an nn.LayerNorm over c = C / p^2 channels, with the rearrangement done by
+    the LayerNorm kernel's addressing instead of a copy (PatchExpand / FinalPatchExpand_X4, mamba_sys.py:233-265)."""
+    c = x.shape[-1] // (p * p)
+    if (isinstance(module, torch.nn.LayerNorm) and x.is_cuda and x.dim() == 4 and x.shape[-1] == p * p * c and c % 4 == 0
+            and c <= 1536 and module.weight is not None and module.bias is not None and tuple(module.normalized_shape) == (c,)):
+        return _LayerNorm.apply(x, module.weight, module.bias, module.eps, p)
+    return apply_norm(module, pixel_unshuffle_cl(x, p))
 
 
 class _DirsScatter2(torch.autograd.Function):

@@ -16,15 +16,7 @@ import torch
 import torch.nn as nn
 
 from .ss2d import VSSLayer, VSSLayer_up
-from .ss2d_ops import apply_linear, apply_norm
-
-
-def _pixel_unshuffle_cl(x: torch.Tensor, p: int) -> torch.Tensor:
-    """(B, H, W, p*p*c) -> (B, H*p, W*p, c), channel groups ordered (p1, p2, c) -- the einops pattern
-    'b h w (p1 p2 c) -> b (h p1) (w p2) c' of mamba_sys.py:244, :262."""
-    B, H, W, C = x.shape
-    c = C // (p * p)
-    return x.view(B, H, W, p, p, c).permute(0, 1, 3, 2, 4, 5).reshape(B, H * p, W * p, c)
+from .ss2d_ops import apply_linear, apply_norm, apply_norm_unshuffle
 
 
 class PatchEmbed2D(nn.Module):
@@ -71,7 +63,7 @@ class PatchExpand(nn.Module):
         self.norm = norm_layer(dim // dim_scale)
 
     def forward(self, x):
-        return apply_norm(self.norm, _pixel_unshuffle_cl(apply_linear(self.expand, x), 2))
+        return apply_norm_unshuffle(self.norm, apply_linear(self.expand, x), 2)
 
 
 class FinalPatchExpand_X4(nn.Module):
@@ -85,7 +77,7 @@ class FinalPatchExpand_X4(nn.Module):
         self.norm = norm_layer(self.output_dim)
 
     def forward(self, x):
-        return apply_norm(self.norm, _pixel_unshuffle_cl(apply_linear(self.expand, x), self.dim_scale))
+        return apply_norm_unshuffle(self.norm, apply_linear(self.expand, x), self.dim_scale)
 
 
 class VSSM(nn.Module):

@@ -340,3 +340,34 @@ def test_scan_params_kernel(Dm, N, R, regroup):
         assert got.shape == want.shape and rel_l2(got.detach().cpu(), want.detach()) < 1e-6
     for got, want in zip(dev_in, ref_in):
         assert got.grad.shape == want.grad.shape and rel_l2(got.grad.cpu(), want.grad) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,c,p,dtype", [(2, 5, 7, 24, 2, torch.float32), (1, 14, 14, 96, 4, torch.float32),
+                                             (2, 7, 7, 384, 2, torch.float32), (2, 14, 14, 96, 4, torch.bfloat16)])
+def test_layer_norm_over_pixel_unshuffle(B, H, W, c, p, dtype):
+    """LayerNorm(rearrange(x, 'b h w (p1 p2 c) -> b (h p1) (w p2) c')) (mamba_sys.py:244-247, :262-265) with the
+    rearrangement done by the kernel's row addressing: against torch on the rearranged copy, fp64."""
+    from mamba_unet_amd.ss2d_ops import apply_norm_unshuffle, pixel_unshuffle_cl
+    gen = torch.Generator().manual_seed(c + p)
+    x = torch.randn(B, H, W, p * p * c, generator=gen).to(dtype).float()
+    ln = torch.nn.LayerNorm(c)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(c, generator=gen) + 0.5)
+        ln.bias.copy_(torch.randn(c, generator=gen) * 0.1)
+    go = torch.randn(B, H * p, W * p, c, generator=gen).to(dtype).float()
+    xr = x.double().requires_grad_(True)
+    lr = torch.nn.LayerNorm(c).double()
+    lr.load_state_dict(ln.state_dict())
+    ref = lr(pixel_unshuffle_cl(xr, p))
+    ref.backward(go.double())
+    ld = torch.nn.LayerNorm(c).cuda()
+    ld.load_state_dict(ln.state_dict())
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    out = apply_norm_unshuffle(ld, xd, p)
+    assert out.shape == (B, H * p, W * p, c) and out.dtype == dtype
+    out.backward(go.cuda().to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(out.detach().float().cpu(), ref.detach()) < tol
+    assert rel_l2(xd.grad.float().cpu(), xr.grad) < tol
+    assert rel_l2(ld.weight.grad.cpu(), lr.weight.grad) < (1e-5 if dtype == torch.float32 else 2e-3)
+    assert rel_l2(ld.bias.grad.cpu(), lr.bias.grad) < (1e-5 if dtype == torch.float32 else 2e-3)
