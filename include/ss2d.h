@@ -195,6 +195,20 @@ int ss2d_layernorm_unshuffle_bwd(int in_dtype, int out_dtype, const void *dout, 
                                  const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta,
                                  long long batch, int H, int W, int ps, int D, void *stream);
 
+/* LayerNorm + segmentation head in one pass: the tail of VSSM.up_x4 (mamba_sys.py:859-866) = FinalPatchExpand_X4's
+ * rearrange + norm (:262-265), permute to (B, C, H', W') and the bias-free 1x1 Conv2d(C -> classes) `output` (:789):
+ *   logits[b, k, h', w'] = sum_c w_head[k][c] * LN(unshuffle(x))[b, h', w', c]       H' = H*ps, W' = W*ps
+ * x (batch, H, W, ps*ps*D) in in_dtype, w_head (classes, D) fp32, logits / dlogits (batch, classes, H', W') in
+ * out_dtype; D <= 128, classes <= 16.  The normalised tensor is never materialised.  _bwd: dx in the layout of x;
+ * dgamma, dbeta, dw_head (classes, D) ACCUMULATED INTO (caller zero-fills). */
+int ss2d_ln_head_fwd(int in_dtype, int out_dtype, const void *x, const float *gamma, const float *beta,
+                     const float *w_head, void *logits, float *mean, float *rstd, long long batch, int H, int W, int ps,
+                     int D, int classes, float eps, void *stream);
+int ss2d_ln_head_bwd(int in_dtype, int out_dtype, const void *dlogits, const void *x, const float *gamma,
+                     const float *beta, const float *w_head, const float *mean, const float *rstd, void *dx,
+                     float *dgamma, float *dbeta, float *dw_head, long long batch, int H, int W, int ps, int D,
+                     int classes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,152 @@ extern "C" int ss2d_layernorm_bwd(int in_dtype, int out_dtype, const void *dout,
     return dispatch(true, in_dtype, out_dtype, p, stream, "layernorm_bwd");
 }
 
+// ---- LayerNorm + segmentation head in one pass (the tail of VSSM.up_x4, mamba_sys.py:859-866: FinalPatchExpand_X4's
+// norm over the 4x4 un-shuffled rows, permute to (B, C, H, W), 1x1 Conv2d(C -> classes, bias=False)).
+//     logits[b, k, h', w'] = sum_c Wh[k][c] * LN(x)[b, h', w', c]
+// The normalised tensor (231 MB at 224x224, batch 24) is never written: the forward reads x once and writes the
+// 4-channel logits; the backward re-normalises x on the fly, expands dlogits through Wh^T into the LayerNorm
+// backward and accumulates dWh next to dgamma / dbeta.  D <= 128 (two rows per wave, a 4-element chunk per lane).
+namespace {
+
+struct HeadParams {
+    const float *wh;     // (nc, D) fp32
+    const void *glog;    // bwd: dlogits (B, nc, H', W') in the out dtype
+    void *logits;        // fwd
+    float *dwh;          // bwd: (nc, D) fp32, accumulated into
+    int nc;
+    long long plane;     // H' * W'
+};
+
+template <int NCP, typename TI, typename TO>
+__global__ __launch_bounds__(256) void ln_head_fwd_kernel(const LNParams p, const HeadParams hp) {
+    constexpr int LW = 32;
+    const int lane = threadIdx.x & (LW - 1);
+    const long long wave0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((threadIdx.x & 63) / LW);
+    const long long nwaves = (long long)gridDim.x * 4 * 2;
+    const int D = p.D, nchunk = D >> 2;
+    const TI *__restrict__ X = static_cast<const TI *>(p.x);
+    TO *__restrict__ LG = static_cast<TO *>(hp.logits);
+    const bool act = lane < nchunk;
+    const f4 g = act ? ld4(p.gamma + 4 * lane) : f4{0, 0, 0, 0};
+    const f4 b = act ? ld4(p.beta + 4 * lane) : f4{0, 0, 0, 0};
+    f4 wv[NCP];
+#pragma unroll
+    for (int k = 0; k < NCP; ++k) wv[k] = (act && k < hp.nc) ? ld4(hp.wh + (size_t)k * D + 4 * lane) : f4{0, 0, 0, 0};
+    const float invD = 1.0f / (float)D;
+    for (long long r = wave0; r < p.rows; r += nwaves) {
+        const f4 xv = act ? ld4(X + ln_row_off(p, r) + 4 * lane) : f4{0, 0, 0, 0};
+        const float mu = wave_sum_ln<LW>((xv.x + xv.y) + (xv.z + xv.w)) * invD;
+        const f4 d = act ? xv - mu : f4{0, 0, 0, 0};
+        const float rstd = __builtin_amdgcn_rsqf(wave_sum_ln<LW>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * invD + p.eps);
+        if (lane == 0 && p.mean) { p.mean[r] = mu; p.rstd[r] = rstd; }
+        const f4 y = d * rstd * g + b;      // zero on the inactive lanes (g = b = 0 there)
+        const long long bi = r / hp.plane, pix = r - bi * hp.plane;
+#pragma unroll
+        for (int k = 0; k < NCP; ++k) {
+            const f4 t = y * wv[k];
+            const float sk = wave_sum_ln<LW>((t.x + t.y) + (t.z + t.w));
+            if (lane == 0 && k < hp.nc) st1(LG + (bi * hp.nc + k) * hp.plane + pix, sk);
+        }
+    }
+}
+
+template <int NCP, typename TI, typename TO>
+__global__ __launch_bounds__(1024) void ln_head_bwd_kernel(const LNParams p, const HeadParams hp) {
+    constexpr int LW = 32, NWV = 16;
+    __shared__ __attribute__((aligned(16))) float red[NWV * 2 * 256];
+    const int lane = threadIdx.x & (LW - 1);
+    const long long wave0 = ((long long)blockIdx.x * NWV + (threadIdx.x >> 6)) * 2 + ((threadIdx.x & 63) / LW);
+    const long long nwaves = (long long)gridDim.x * NWV * 2;
+    const int D = p.D, nchunk = D >> 2;
+    const TI *__restrict__ X = static_cast<const TI *>(p.x);
+    const TO *__restrict__ GL = static_cast<const TO *>(hp.glog);
+    TI *__restrict__ DX = static_cast<TI *>(p.dx);
+    const bool act = lane < nchunk;
+    const f4 g = act ? ld4(p.gamma + 4 * lane) : f4{0, 0, 0, 0};
+    const f4 b = act ? ld4(p.beta + 4 * lane) : f4{0, 0, 0, 0};
+    f4 wv[NCP], aw[NCP], ag[1] = {f4{0, 0, 0, 0}}, ab[1] = {f4{0, 0, 0, 0}};
+#pragma unroll
+    for (int k = 0; k < NCP; ++k) {
+        wv[k] = (act && k < hp.nc) ? ld4(hp.wh + (size_t)k * D + 4 * lane) : f4{0, 0, 0, 0};
+        aw[k] = f4{0, 0, 0, 0};
+    }
+    const float invD = 1.0f / (float)D;
+    for (long long r = wave0; r < p.rows; r += nwaves) {
+        const long long xoff = ln_row_off(p, r);
+        const long long bi = r / hp.plane, pix = r - bi * hp.plane;
+        const float mu = p.mean_in[r], rstd = p.rstd_in[r];
+        const f4 xv = act ? ld4(X + xoff + 4 * lane) : f4{0, 0, 0, 0};
+        float gk[NCP];
+#pragma unroll
+        for (int k = 0; k < NCP; ++k) gk[k] = ld1(GL + (bi * hp.nc + (k < hp.nc ? k : hp.nc - 1)) * hp.plane + pix);   // same address on the 32 lanes of a row
+        const f4 nh = act ? (xv - mu) * rstd : f4{0, 0, 0, 0};
+        const f4 y = nh * g + b;
+        f4 dout = f4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < NCP; ++k) {
+            const float gv = k < hp.nc ? gk[k] : 0.0f;
+            dout += wv[k] * gv;        // dL/dLN(x) = Wh^T dlogits
+            aw[k] += y * gv;           // dWh[k] += dlogits[k] * LN(x)
+        }
+        const f4 dn = dout * g;
+        ag[0] += dout * nh;
+        ab[0] += dout;
+        const f4 t = dn * nh;
+        const float m1 = wave_sum_ln<LW>((dn.x + dn.y) + (dn.z + dn.w)) * invD;
+        const float m2 = wave_sum_ln<LW>((t.x + t.y) + (t.z + t.w)) * invD;
+        if (act) st4(DX + xoff + 4 * lane, (dn - m1 - nh * m2) * rstd);
+    }
+    wg_colsum2<1, NWV, LW>(red, ag, ab, D, p.dgamma, p.dbeta);
+#pragma unroll
+    for (int k = 0; k < NCP; k += 2) {
+        __syncthreads();   // the previous pair's sums have been read
+        f4 a0[1] = {aw[k]}, a1[1] = {k + 1 < NCP ? aw[k + 1] : f4{0, 0, 0, 0}};
+        // rows past nc hold zeros; their (harmless) atomics go to the last real row
+        const int k0 = k < hp.nc ? k : hp.nc - 1, k1 = k + 1 < hp.nc ? k + 1 : hp.nc - 1;
+        wg_colsum2<1, NWV, LW>(red, a0, a1, D, hp.dwh + (size_t)k0 * D, hp.dwh + (size_t)k1 * D);
+    }
+}
+
+template <typename TI, typename TO>
+int launch_head(bool bwd, const LNParams &p, const HeadParams &hp, hipStream_t s) {
+    const int ncp = hp.nc <= 4 ? 4 : (hp.nc <= 10 ? 10 : 16);
+    if (!bwd) {
+        long long nwg = (p.rows + 7) / 8;
+        if (nwg > 8192) nwg = 8192;
+        const dim3 grid((unsigned)nwg), block(256);
+        if (ncp == 4) hipLaunchKernelGGL((ln_head_fwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
+        else if (ncp == 10) hipLaunchKernelGGL((ln_head_fwd_kernel<10, TI, TO>), grid, block, 0, s, p, hp);
+        else hipLaunchKernelGGL((ln_head_fwd_kernel<16, TI, TO>), grid, block, 0, s, p, hp);
+    } else {
+        long long nwg = (p.rows + 31) / 32;
+        if (nwg > 256) nwg = 256;
+        const dim3 grid((unsigned)nwg), block(1024);
+        if (ncp == 4) hipLaunchKernelGGL((ln_head_bwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
+        else if (ncp == 10) hipLaunchKernelGGL((ln_head_bwd_kernel<10, TI, TO>), grid, block, 0, s, p, hp);
+        else hipLaunchKernelGGL((ln_head_bwd_kernel<16, TI, TO>), grid, block, 0, s, p, hp);
+    }
+    return (int)hipGetLastError();
+}
+
+int dispatch_head(bool bwd, int in_dtype, int out_dtype, const LNParams &p, const HeadParams &hp, void *stream, const char *name) {
+    if ((in_dtype != SS2D_DTYPE_F32 && in_dtype != SS2D_DTYPE_BF16) || (out_dtype != SS2D_DTYPE_F32 && out_dtype != SS2D_DTYPE_BF16)) {
+        ss2d_set_error("%s: unknown dtype %d / %d", name, in_dtype, out_dtype); return -1; }
+    if (in_dtype == SS2D_DTYPE_BF16 && out_dtype == SS2D_DTYPE_F32) { ss2d_set_error("%s: bf16 input with fp32 output is not supported", name); return -1; }
+    if (p.rows <= 0 || p.D <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
+    if (p.D % 4 || p.D > 128) { ss2d_set_error("%s: D %d must be a multiple of 4 and <= 128", name, p.D); return -4; }
+    if (hp.nc <= 0 || hp.nc > 16) { ss2d_set_error("%s: classes %d must be in 1..16", name, hp.nc); return -4; }
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (in_dtype == SS2D_DTYPE_F32 && out_dtype == SS2D_DTYPE_F32) rc = launch_head<float, float>(bwd, p, hp, s);
+    else if (in_dtype == SS2D_DTYPE_F32) rc = launch_head<float, bf16>(bwd, p, hp, s);
+    else rc = launch_head<bf16, bf16>(bwd, p, hp, s);
+    if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
+}  // namespace
+
 // LayerNorm over the rows of a ps x ps pixel un-shuffle of x (PatchExpand / FinalPatchExpand_X4, mamba_sys.py:233-265)
 static int check_ps(long long batch, int H, int W, int ps, const char *name) {
     if (batch <= 0 || H <= 0 || W <= 0 || ps <= 0 || ps > 8) { ss2d_set_error("%s: bad un-shuffle geometry (batch %lld, H %d, W %d, ps %d)", name, batch, H, W, ps); return -3; }
@@ -244,4 +390,33 @@ extern "C" int ss2d_layernorm_unshuffle_bwd(int in_dtype, int out_dtype, const v
     p.dout = dout; p.x = x; p.gamma = gamma; p.mean_in = mean; p.rstd_in = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
     p.D = D; p.rows = batch * H * ps * W * ps; p.ps = ps; p.psH = H; p.psW = W;
     return dispatch(true, in_dtype, out_dtype, p, stream, "layernorm_unshuffle_bwd");
+}
+
+extern "C" int ss2d_ln_head_fwd(int in_dtype, int out_dtype, const void *x, const float *gamma, const float *beta,
+                                const float *w_head, void *logits, float *mean, float *rstd, long long batch, int H, int W,
+                                int ps, int D, int classes, float eps, void *stream) {
+    if (!x || !gamma || !beta || !w_head || !logits) { ss2d_set_error("ln_head_fwd: null pointer"); return -2; }
+    if ((mean == nullptr) != (rstd == nullptr)) { ss2d_set_error("ln_head_fwd: mean and rstd go together"); return -2; }
+    if (int rc = check_ps(batch, H, W, ps, "ln_head_fwd")) return rc;
+    LNParams p{};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.mean = mean; p.rstd = rstd; p.D = D; p.eps = eps;
+    p.rows = batch * H * ps * W * ps; p.ps = ps; p.psH = H; p.psW = W;
+    HeadParams hp{};
+    hp.wh = w_head; hp.logits = logits; hp.nc = classes; hp.plane = (long long)H * ps * W * ps;
+    return dispatch_head(false, in_dtype, out_dtype, p, hp, stream, "ln_head_fwd");
+}
+
+extern "C" int ss2d_ln_head_bwd(int in_dtype, int out_dtype, const void *dlogits, const void *x, const float *gamma,
+                                const float *beta, const float *w_head, const float *mean, const float *rstd, void *dx,
+                                float *dgamma, float *dbeta, float *dw_head, long long batch, int H, int W, int ps, int D,
+                                int classes, void *stream) {
+    if (!dlogits || !x || !gamma || !beta || !w_head || !mean || !rstd || !dx || !dgamma || !dbeta || !dw_head) {
+        ss2d_set_error("ln_head_bwd: null pointer"); return -2; }
+    if (int rc = check_ps(batch, H, W, ps, "ln_head_bwd")) return rc;
+    LNParams p{};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.mean_in = mean; p.rstd_in = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.D = D; p.rows = batch * H * ps * W * ps; p.ps = ps; p.psH = H; p.psW = W;
+    HeadParams hp{};
+    hp.wh = w_head; hp.glog = dlogits; hp.dwh = dw_head; hp.nc = classes; hp.plane = (long long)H * ps * W * ps;
+    return dispatch_head(true, in_dtype, out_dtype, p, hp, stream, "ln_head_bwd");
 }

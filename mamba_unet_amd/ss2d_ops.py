@@ -501,3 +501,63 @@ def scan_params(A_logs: torch.Tensor, Ds: torch.Tensor, dt_projs_bias: torch.Ten
     (A = -exp(A_logs) (K*D, N), D (K*D), delta_bias (K*D), dt weight (K, D, R)), fp32; with `regroup` in the
     scan-group order (row-major, row-major reversed, column-major, column-major reversed) of `scan_merge_fn`."""
     return _ScanParams.apply(A_logs, Ds, dt_projs_bias, dt_projs_weight, regroup)
+
+
+class _LNHead(torch.autograd.Function):
+    """logits = Conv1x1(LN(pixel_unshuffle(x))) in one pass each way (csrc/ss2d_layernorm.hip, ln_head_*): the tail of
+    VSSM.up_x4 (mamba_sys.py:859-866).  x (B, H, W, ps*ps*c) -> (B, classes, H*ps, W*ps)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, ps, w_head):
+        _need_gpu(x, "ln_head")
+        io, code = _io(x)
+        B, H, W, C = x.shape
+        D, nc = C // (ps * ps), w_head.shape[0]
+        x2 = x.to(io)
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        out_bf16 = io == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        ocode, odt = (_BF16, torch.bfloat16) if out_bf16 else (_F32, torch.float32)
+        g32, b32 = gamma.float().contiguous(), beta.float().contiguous()
+        w32 = w_head.float().reshape(nc, D).contiguous()
+        rows = B * H * ps * W * ps
+        logits = torch.empty((B, nc, H * ps, W * ps), device=x.device, dtype=odt)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        with torch.cuda.device(x.device):
+            rc = _lib.load().ss2d_ln_head_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(w32),
+                                              _lib.ptr(logits), _lib.ptr(mean), _lib.ptr(rstd), B, H, W, ps, D, nc,
+                                              float(eps), _stream())
+        _lib.check(rc, "ss2d_ln_head_fwd")
+        ctx.save_for_backward(x2, g32, b32, w32, mean, rstd)
+        ctx.meta = (code, ocode, odt, ps, x.shape, x.dtype, gamma.dtype, beta.dtype, w_head.dtype, tuple(w_head.shape))
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        x2, g32, b32, w32, mean, rstd = ctx.saved_tensors
+        code, ocode, odt, ps, xshape, xdt, gdt, bdt, wdt, wshape = ctx.meta
+        B, H, W, C = xshape
+        nc, D = w32.shape
+        g = dlogits.to(odt)
+        g = g if g.is_contiguous() else g.contiguous()
+        dx = torch.empty_like(x2)
+        dg, db, dw = _lib.zeros_group(g.device, (D,), (D,), (nc, D))
+        with torch.cuda.device(g.device):
+            rc = _lib.load().ss2d_ln_head_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(w32),
+                                              _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db),
+                                              _lib.ptr(dw), B, H, W, ps, D, nc, _stream())
+        _lib.check(rc, "ss2d_ln_head_bwd")
+        return dx.view(xshape).to(xdt), dg.to(gdt), db.to(bdt), None, None, dw.view(wshape).to(wdt)
+
+
+def ln_unshuffle_head(norm: torch.nn.Module, x: torch.Tensor, p: int, conv: torch.nn.Module) -> torch.Tensor:
+    """conv(norm(pixel_unshuffle_cl(x, p)).permute(0, 3, 1, 2)) for an nn.LayerNorm and a bias-free 1x1 nn.Conv2d, fused
+    when the shapes allow (c <= 128, classes <= 16); the separate kernels otherwise."""
+    c = x.shape[-1] // (p * p)
+    if (isinstance(norm, torch.nn.LayerNorm) and isinstance(conv, torch.nn.Conv2d) and x.is_cuda and x.dim() == 4
+            and x.shape[-1] == p * p * c and c % 4 == 0 and c <= 128 and tuple(norm.normalized_shape) == (c,)
+            and norm.weight is not None and norm.bias is not None and conv.bias is None and conv.kernel_size == (1, 1)
+            and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1 and conv.in_channels == c
+            and conv.out_channels <= 16):
+        return _LNHead.apply(x, norm.weight, norm.bias, norm.eps, p, conv.weight)
+    return conv(apply_norm_unshuffle(norm, x, p).permute(0, 3, 1, 2))

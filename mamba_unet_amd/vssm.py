@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .ss2d import VSSLayer, VSSLayer_up
-from .ss2d_ops import apply_linear, apply_norm, apply_norm_unshuffle
+from .ss2d_ops import apply_linear, apply_norm, apply_norm_unshuffle, ln_unshuffle_head
 
 
 class PatchEmbed2D(nn.Module):
@@ -159,9 +159,9 @@ class VSSM(nn.Module):
 
     def up_x4(self, x):
         if self.final_upsample == "expand_first":
-            B, H, W, _ = x.shape
-            x = self.up(x).view(B, 4 * H, 4 * W, -1).permute(0, 3, 1, 2)
-            x = self.output(x)
+            # FinalPatchExpand_X4 (expand, 4x4 un-shuffle, norm) + permute + 1x1 `output` conv; norm and conv run as
+            # one kernel that never writes the (B, 4H, 4W, C) tensor between them
+            x = ln_unshuffle_head(self.up.norm, apply_linear(self.up.expand, x), self.up.dim_scale, self.output)
         return x
 
     def forward(self, x):

@@ -371,3 +371,37 @@ def test_layer_norm_over_pixel_unshuffle(B, H, W, c, p, dtype):
     assert rel_l2(xd.grad.float().cpu(), xr.grad) < tol
     assert rel_l2(ld.weight.grad.cpu(), lr.weight.grad) < (1e-5 if dtype == torch.float32 else 2e-3)
     assert rel_l2(ld.bias.grad.cpu(), lr.bias.grad) < (1e-5 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("B,H,W,c,p,nc,dtype", [(2, 5, 7, 24, 2, 4, torch.float32), (1, 14, 14, 96, 4, 4, torch.float32),
+                                                (2, 6, 5, 96, 4, 9, torch.float32), (1, 4, 4, 128, 4, 16, torch.float32),
+                                                (2, 14, 14, 96, 4, 4, torch.bfloat16)])
+def test_ln_unshuffle_head_fused(B, H, W, c, p, nc, dtype):
+    """1x1 conv (bias-free) of LayerNorm(rearrange(x)) in one pass each way against torch on the materialised
+    tensors in fp64 (the tail of VSSM.up_x4, mamba_sys.py:859-866)."""
+    from mamba_unet_amd.ss2d_ops import ln_unshuffle_head, pixel_unshuffle_cl
+    gen = torch.Generator().manual_seed(c + p + nc)
+    x = torch.randn(B, H, W, p * p * c, generator=gen).to(dtype).float()
+    ln, conv = torch.nn.LayerNorm(c), torch.nn.Conv2d(c, nc, 1, bias=False)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(c, generator=gen) + 0.5)
+        ln.bias.copy_(torch.randn(c, generator=gen) * 0.1)
+        conv.weight.copy_(torch.randn(nc, c, 1, 1, generator=gen) * 0.2)
+    go = torch.randn(B, nc, H * p, W * p, generator=gen).to(dtype).float()
+    xr = x.double().requires_grad_(True)
+    lr, cr = torch.nn.LayerNorm(c).double(), torch.nn.Conv2d(c, nc, 1, bias=False).double()
+    lr.load_state_dict(ln.state_dict()); cr.load_state_dict(conv.state_dict())
+    ref = cr(lr(pixel_unshuffle_cl(xr, p)).permute(0, 3, 1, 2))
+    ref.backward(go.double())
+    ld, cd = torch.nn.LayerNorm(c).cuda(), torch.nn.Conv2d(c, nc, 1, bias=False).cuda()
+    ld.load_state_dict(ln.state_dict()); cd.load_state_dict(conv.state_dict())
+    xd = x.cuda().to(dtype).requires_grad_(True)
+    out = ln_unshuffle_head(ld, xd, p, cd)
+    assert out.shape == (B, nc, H * p, W * p) and out.dtype == dtype
+    out.backward(go.cuda().to(dtype))
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    ptol = 1e-5 if dtype == torch.float32 else 3e-3
+    assert rel_l2(out.detach().float().cpu(), ref.detach()) < tol
+    assert rel_l2(xd.grad.float().cpu(), xr.grad) < tol
+    assert rel_l2(ld.weight.grad.cpu(), lr.weight.grad) < ptol and rel_l2(ld.bias.grad.cpu(), lr.bias.grad) < ptol
+    assert rel_l2(cd.weight.grad.cpu(), cr.weight.grad) < ptol
