@@ -234,35 +234,97 @@ struct HeadParams {
     long long plane;     // H' * W'
 };
 
+// Sum over the 32 lanes of this lane's half-wave, result in every lane: four rotate-and-add DPP steps inside each
+// 16-lane row (VALU), then the two row totals of the half through v_readlane.  The ds_bpermute butterfly
+// (wave_sum_ln) is five LDS-pipe instructions per sum, and with six sums per row that pipe, not memory, bounded
+// the fused head kernels.
+__device__ __forceinline__ float half_sum32(float v, int half) {
+    v += dpp_mov<DPP_ROW_ROR(8), 0xf, false>(0.0f, v);
+    v += dpp_mov<DPP_ROW_ROR(4), 0xf, false>(0.0f, v);
+    v += dpp_mov<DPP_ROW_ROR(2), 0xf, false>(0.0f, v);
+    v += dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, v);
+    const int iv = __builtin_bit_cast(int, v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return half ? c : a;
+}
+
+// value of lane `it` of this lane's 32-lane half (it is wave-uniform): two v_readlane + a select, no LDS
+__device__ __forceinline__ float half_bcast(float v, int it, int half) {
+    const int iv = __builtin_bit_cast(int, v);
+    const int a = __builtin_amdgcn_readlane(iv, it), b = __builtin_amdgcn_readlane(iv, it + 32);
+    return __builtin_bit_cast(float, half ? b : a);
+}
+__device__ __forceinline__ f4 zero_unless(f4 v, bool keep) { return keep ? v : f4{0, 0, 0, 0}; }
+
+// Walks consecutive output rows of the un-shuffled image without a division per row: the 64-bit div / mod chain of
+// ln_row_off (three of them, each a branchy software routine) is done once per 32-row run in 32-bit arithmetic,
+// then the (b, h, p1, w, p2) counters are stepped.  off() = element offset of the row in x.
+struct RowIter {
+    int b, h, p1, w, p2;
+    __device__ __forceinline__ RowIter(const LNParams &p, long long r) {
+        const unsigned W4 = (unsigned)(p.psW * p.ps), H4 = (unsigned)(p.psH * p.ps), ur = (unsigned)r;   // rows < 2^31 (host check)
+        const unsigned w4 = ur % W4, t = ur / W4, h4 = t % H4;
+        b = (int)(t / H4); h = (int)(h4 / (unsigned)p.ps); p1 = (int)(h4 % (unsigned)p.ps);
+        w = (int)(w4 / (unsigned)p.ps); p2 = (int)(w4 % (unsigned)p.ps);
+    }
+    __device__ __forceinline__ long long off(const LNParams &p) const {
+        return ((((long long)(b * p.psH + h) * p.psW + w) * p.ps + p1) * p.ps + p2) * (long long)p.D;
+    }
+    __device__ __forceinline__ void next(const LNParams &p) {
+        if (++p2 == p.ps) { p2 = 0; if (++w == p.psW) { w = 0; if (++p1 == p.ps) { p1 = 0; if (++h == p.psH) { h = 0; ++b; } } } }
+    }
+};
+
+// A wave walks blocks of 64 consecutive rows, 32 per half-wave, one row per trip; lane l of a half keeps the
+// per-row results (mean, rstd, logits) of trip l, so they leave as coalesced 64-byte stores once per block, and
+// in the backward the per-row inputs (mean, rstd, dlogits) arrive as coalesced loads and are broadcast from
+// registers -- one-lane stores / same-address loads per row cost more than the 231 MB of row data.
 template <int NCP, typename TI, typename TO>
 __global__ __launch_bounds__(256) void ln_head_fwd_kernel(const LNParams p, const HeadParams hp) {
     constexpr int LW = 32;
-    const int lane = threadIdx.x & (LW - 1);
-    const long long wave0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + ((threadIdx.x & 63) / LW);
-    const long long nwaves = (long long)gridDim.x * 4 * 2;
+    const int lane = threadIdx.x & (LW - 1), half = (threadIdx.x & 63) >> 5;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
     const int D = p.D, nchunk = D >> 2;
     const TI *__restrict__ X = static_cast<const TI *>(p.x);
     TO *__restrict__ LG = static_cast<TO *>(hp.logits);
     const bool act = lane < nchunk;
-    const f4 g = act ? ld4(p.gamma + 4 * lane) : f4{0, 0, 0, 0};
-    const f4 b = act ? ld4(p.beta + 4 * lane) : f4{0, 0, 0, 0};
+    const int cl = act ? lane : nchunk - 1;
+    const f4 g = zero_unless(ld4(p.gamma + 4 * cl), act), b = zero_unless(ld4(p.beta + 4 * cl), act);
     f4 wv[NCP];
 #pragma unroll
-    for (int k = 0; k < NCP; ++k) wv[k] = (act && k < hp.nc) ? ld4(hp.wh + (size_t)k * D + 4 * lane) : f4{0, 0, 0, 0};
+    for (int k = 0; k < NCP; ++k) wv[k] = zero_unless(ld4(hp.wh + (size_t)(k < hp.nc ? k : hp.nc - 1) * D + 4 * cl), act && k < hp.nc);
     const float invD = 1.0f / (float)D;
-    for (long long r = wave0; r < p.rows; r += nwaves) {
-        const f4 xv = act ? ld4(X + ln_row_off(p, r) + 4 * lane) : f4{0, 0, 0, 0};
-        const float mu = wave_sum_ln<LW>((xv.x + xv.y) + (xv.z + xv.w)) * invD;
-        const f4 d = act ? xv - mu : f4{0, 0, 0, 0};
-        const float rstd = __builtin_amdgcn_rsqf(wave_sum_ln<LW>((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w)) * invD + p.eps);
-        if (lane == 0 && p.mean) { p.mean[r] = mu; p.rstd[r] = rstd; }
-        const f4 y = d * rstd * g + b;      // zero on the inactive lanes (g = b = 0 there)
-        const long long bi = r / hp.plane, pix = r - bi * hp.plane;
+    for (long long r0 = wid * 64; r0 < p.rows; r0 += nw * 64) {
+        float keep[NCP], kmu = 0.0f, krs = 0.0f;
 #pragma unroll
-        for (int k = 0; k < NCP; ++k) {
-            const f4 t = y * wv[k];
-            const float sk = wave_sum_ln<LW>((t.x + t.y) + (t.z + t.w));
-            if (lane == 0 && k < hp.nc) st1(LG + (bi * hp.nc + k) * hp.plane + pix, sk);
+        for (int k = 0; k < NCP; ++k) keep[k] = 0.0f;
+        RowIter ri(p, r0 + half * 32);
+        const int nvalid = (int)((p.rows - (r0 + half * 32)) < 32 ? (p.rows - (r0 + half * 32)) : 32);   // <= 0: nothing stored
+        long long xoff = nvalid > 0 ? ri.off(p) : 0;
+#pragma unroll 4
+        for (int it = 0; it < 32; ++it) {
+            const f4 xv = zero_unless(ld4(X + xoff + 4 * cl), act);
+            if (it + 1 < nvalid) { ri.next(p); xoff = ri.off(p); }   // past the end: the last row again, never stored
+            const float mu = half_sum32((xv.x + xv.y) + (xv.z + xv.w), half) * invD;
+            const f4 d = zero_unless(xv - mu, act);
+            const float rstd = __builtin_amdgcn_rsqf(half_sum32((d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w), half) * invD + p.eps);
+            const f4 y = d * rstd * g + b;      // zero on the inactive lanes (g = b = 0 there)
+            if (lane == it) { kmu = mu; krs = rstd; }
+#pragma unroll
+            for (int k = 0; k < NCP; ++k) {
+                const f4 t = y * wv[k];
+                const float sk = half_sum32((t.x + t.y) + (t.z + t.w), half);
+                if (lane == it) keep[k] = sk;
+            }
+        }
+        const long long r = r0 + half * 32 + lane;   // the row whose results this lane kept
+        if (r < p.rows) {
+            if (p.mean) { p.mean[r] = kmu; p.rstd[r] = krs; }
+            const long long bi = r / hp.plane, pix = r - bi * hp.plane;
+#pragma unroll
+            for (int k = 0; k < NCP; ++k)
+                if (k < hp.nc) st1(LG + (bi * hp.nc + k) * hp.plane + pix, keep[k]);
         }
     }
 }
@@ -271,47 +333,62 @@ template <int NCP, typename TI, typename TO>
 __global__ __launch_bounds__(1024) void ln_head_bwd_kernel(const LNParams p, const HeadParams hp) {
     constexpr int LW = 32, NWV = 16;
     __shared__ __attribute__((aligned(16))) float red[NWV * 2 * 256];
-    const int lane = threadIdx.x & (LW - 1);
-    const long long wave0 = ((long long)blockIdx.x * NWV + (threadIdx.x >> 6)) * 2 + ((threadIdx.x & 63) / LW);
-    const long long nwaves = (long long)gridDim.x * NWV * 2;
+    const int lane = threadIdx.x & (LW - 1), half = (threadIdx.x & 63) >> 5;
+    const long long wid = (long long)blockIdx.x * NWV + (threadIdx.x >> 6), nw = (long long)gridDim.x * NWV;
     const int D = p.D, nchunk = D >> 2;
     const TI *__restrict__ X = static_cast<const TI *>(p.x);
     const TO *__restrict__ GL = static_cast<const TO *>(hp.glog);
     TI *__restrict__ DX = static_cast<TI *>(p.dx);
     const bool act = lane < nchunk;
-    const f4 g = act ? ld4(p.gamma + 4 * lane) : f4{0, 0, 0, 0};
-    const f4 b = act ? ld4(p.beta + 4 * lane) : f4{0, 0, 0, 0};
+    const int cl = act ? lane : nchunk - 1;
+    const f4 g = zero_unless(ld4(p.gamma + 4 * cl), act), b = zero_unless(ld4(p.beta + 4 * cl), act);
     f4 wv[NCP], aw[NCP], ag[1] = {f4{0, 0, 0, 0}}, ab[1] = {f4{0, 0, 0, 0}};
 #pragma unroll
     for (int k = 0; k < NCP; ++k) {
-        wv[k] = (act && k < hp.nc) ? ld4(hp.wh + (size_t)k * D + 4 * lane) : f4{0, 0, 0, 0};
+        wv[k] = zero_unless(ld4(hp.wh + (size_t)(k < hp.nc ? k : hp.nc - 1) * D + 4 * cl), act && k < hp.nc);
         aw[k] = f4{0, 0, 0, 0};
     }
     const float invD = 1.0f / (float)D;
-    for (long long r = wave0; r < p.rows; r += nwaves) {
-        const long long xoff = ln_row_off(p, r);
-        const long long bi = r / hp.plane, pix = r - bi * hp.plane;
-        const float mu = p.mean_in[r], rstd = p.rstd_in[r];
-        const f4 xv = act ? ld4(X + xoff + 4 * lane) : f4{0, 0, 0, 0};
-        float gk[NCP];
-#pragma unroll
-        for (int k = 0; k < NCP; ++k) gk[k] = ld1(GL + (bi * hp.nc + (k < hp.nc ? k : hp.nc - 1)) * hp.plane + pix);   // same address on the 32 lanes of a row
-        const f4 nh = act ? (xv - mu) * rstd : f4{0, 0, 0, 0};
-        const f4 y = nh * g + b;
-        f4 dout = f4{0, 0, 0, 0};
+    for (long long r0 = wid * 64; r0 < p.rows; r0 += nw * 64) {
+        // this lane's row of the block: its mean, rstd and dlogits, read coalesced, broadcast per trip below
+        const long long rl = r0 + half * 32 + lane;
+        const bool lok = rl < p.rows;
+        const long long rlc = lok ? rl : p.rows - 1;
+        const long long lbi = rlc / hp.plane, lpix = rlc - lbi * hp.plane;
+        const float lmu = p.mean_in[rlc], lrs = p.rstd_in[rlc];
+        float lg[NCP];
 #pragma unroll
         for (int k = 0; k < NCP; ++k) {
-            const float gv = k < hp.nc ? gk[k] : 0.0f;
-            dout += wv[k] * gv;        // dL/dLN(x) = Wh^T dlogits
-            aw[k] += y * gv;           // dWh[k] += dlogits[k] * LN(x)
+            const float v = ld1(GL + (lbi * hp.nc + (k < hp.nc ? k : hp.nc - 1)) * hp.plane + lpix);
+            lg[k] = (lok && k < hp.nc) ? v : 0.0f;      // rows past the end and padded classes contribute nothing
         }
-        const f4 dn = dout * g;
-        ag[0] += dout * nh;
-        ab[0] += dout;
-        const f4 t = dn * nh;
-        const float m1 = wave_sum_ln<LW>((dn.x + dn.y) + (dn.z + dn.w)) * invD;
-        const float m2 = wave_sum_ln<LW>((t.x + t.y) + (t.z + t.w)) * invD;
-        if (act) st4(DX + xoff + 4 * lane, (dn - m1 - nh * m2) * rstd);
+        RowIter ri(p, r0 + half * 32);
+        const int nvalid = (int)((p.rows - (r0 + half * 32)) < 32 ? (p.rows - (r0 + half * 32)) : 32);
+        long long xnext = nvalid > 0 ? ri.off(p) : 0;
+#pragma unroll 2
+        for (int it = 0; it < 32; ++it) {
+            const bool rok = it < nvalid;
+            const long long xoff = xnext;
+            const f4 xv = ld4(X + xoff + 4 * cl);
+            if (it + 1 < nvalid) { ri.next(p); xnext = ri.off(p); }
+            const float mu = half_bcast(lmu, it, half), rstd = half_bcast(lrs, it, half);
+            const f4 nh = zero_unless((xv - mu) * rstd, act);
+            const f4 y = nh * g + b;
+            f4 dout = f4{0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NCP; ++k) {
+                const float gv = half_bcast(lg[k], it, half);
+                dout += wv[k] * gv;        // dL/dLN(x) = Wh^T dlogits
+                aw[k] += y * gv;           // dWh[k] += dlogits[k] * LN(x)
+            }
+            const f4 dn = dout * g;
+            ag[0] += dout * nh;
+            ab[0] += dout;
+            const f4 t = dn * nh;
+            const float m1 = half_sum32((dn.x + dn.y) + (dn.z + dn.w), half) * invD;
+            const float m2 = half_sum32((t.x + t.y) + (t.z + t.w), half) * invD;
+            if (act && rok) st4(DX + xoff + 4 * lane, (dn - m1 - nh * m2) * rstd);
+        }
     }
     wg_colsum2<1, NWV, LW>(red, ag, ab, D, p.dgamma, p.dbeta);
 #pragma unroll
@@ -328,14 +405,14 @@ template <typename TI, typename TO>
 int launch_head(bool bwd, const LNParams &p, const HeadParams &hp, hipStream_t s) {
     const int ncp = hp.nc <= 4 ? 4 : (hp.nc <= 10 ? 10 : 16);
     if (!bwd) {
-        long long nwg = (p.rows + 7) / 8;
+        long long nwg = (p.rows + 255) / 256;      // 64 rows per wave and trip
         if (nwg > 8192) nwg = 8192;
         const dim3 grid((unsigned)nwg), block(256);
         if (ncp == 4) hipLaunchKernelGGL((ln_head_fwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
         else if (ncp == 10) hipLaunchKernelGGL((ln_head_fwd_kernel<10, TI, TO>), grid, block, 0, s, p, hp);
         else hipLaunchKernelGGL((ln_head_fwd_kernel<16, TI, TO>), grid, block, 0, s, p, hp);
     } else {
-        long long nwg = (p.rows + 31) / 32;
+        long long nwg = (p.rows + 1023) / 1024;    // 16 waves x 64 rows
         if (nwg > 256) nwg = 256;
         const dim3 grid((unsigned)nwg), block(1024);
         if (ncp == 4) hipLaunchKernelGGL((ln_head_bwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
@@ -352,6 +429,7 @@ int dispatch_head(bool bwd, int in_dtype, int out_dtype, const LNParams &p, cons
     if (p.rows <= 0 || p.D <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
     if (p.D % 4 || p.D > 128) { ss2d_set_error("%s: D %d must be a multiple of 4 and <= 128", name, p.D); return -4; }
     if (hp.nc <= 0 || hp.nc > 16) { ss2d_set_error("%s: classes %d must be in 1..16", name, hp.nc); return -4; }
+    if (p.rows >= 0x7fffffffLL) { ss2d_set_error("%s: more than 2^31 rows", name); return -6; }
     hipStream_t s = (hipStream_t)stream;
     int rc;
     if (in_dtype == SS2D_DTYPE_F32 && out_dtype == SS2D_DTYPE_F32) rc = launch_head<float, float>(bwd, p, hp, s);
