@@ -147,6 +147,23 @@ __device__ __forceinline__ f4 load4m(const IO *__restrict__ row, int pos, int L,
 // thread-local error string shared by the C-ABI entry points
 void ss2d_set_error(const char *fmt, ...);
 
+// Sum over the 64 lanes of the wave (LW = 64) or over this lane's 32-lane half (LW = 32), result in every lane:
+// four rotate-and-add DPP steps inside each 16-lane row (VALU), then the row totals through v_readlane.  A
+// __shfl_xor butterfly is five or six ds_bpermute (LDS-pipe) instructions per sum, and that pipe rather than HBM
+// bounded the row-per-wave norm kernels.
+template <int LW>
+__device__ __forceinline__ float lanes_sum(float v) {
+    v += dpp_mov<DPP_ROW_ROR(8), 0xf, false>(0.0f, v);
+    v += dpp_mov<DPP_ROW_ROR(4), 0xf, false>(0.0f, v);
+    v += dpp_mov<DPP_ROW_ROR(2), 0xf, false>(0.0f, v);
+    v += dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, v);
+    const int iv = __builtin_bit_cast(int, v);
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    if (LW == 64) return a + c;
+    return (threadIdx.x & 32) ? c : a;
+}
+
 // Workgroup column sums for the dgamma / dbeta of the norm kernels: every lane holds K four-element partial sums of
 // two quantities for column chunk (lane % LW) + LW*k.  Half-waves that share columns (LW = 32) are folded with a
 // lane exchange, every wave stores its partials in its own LDS slot, and after one barrier the threads add the NWV

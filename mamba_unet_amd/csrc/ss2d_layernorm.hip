@@ -40,11 +40,7 @@ __device__ __forceinline__ long long ln_row_off(const LNParams &p, long long r) 
 
 // sum over the LW (64 or 32) lanes that share a row
 template <int LW>
-__device__ __forceinline__ float wave_sum_ln(float v) {
-#pragma unroll
-    for (int o = LW / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum_ln(float v) { return lanes_sum<LW>(v); }
 
 // LW = lanes per row: 64, or 32 (two rows per wave) when a row has at most 32 four-element chunks (D <= 128)
 template <int K, int LW, typename TI, typename TO>
@@ -234,20 +230,7 @@ struct HeadParams {
     long long plane;     // H' * W'
 };
 
-// Sum over the 32 lanes of this lane's half-wave, result in every lane: four rotate-and-add DPP steps inside each
-// 16-lane row (VALU), then the two row totals of the half through v_readlane.  The ds_bpermute butterfly
-// (wave_sum_ln) is five LDS-pipe instructions per sum, and with six sums per row that pipe, not memory, bounded
-// the fused head kernels.
-__device__ __forceinline__ float half_sum32(float v, int half) {
-    v += dpp_mov<DPP_ROW_ROR(8), 0xf, false>(0.0f, v);
-    v += dpp_mov<DPP_ROW_ROR(4), 0xf, false>(0.0f, v);
-    v += dpp_mov<DPP_ROW_ROR(2), 0xf, false>(0.0f, v);
-    v += dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, v);
-    const int iv = __builtin_bit_cast(int, v);
-    const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
-    const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
-    return half ? c : a;
-}
+__device__ __forceinline__ float half_sum32(float v, int) { return lanes_sum<32>(v); }
 
 // value of lane `it` of this lane's 32-lane half (it is wave-uniform): two v_readlane + a select, no LDS
 __device__ __forceinline__ float half_bcast(float v, int it, int half) {

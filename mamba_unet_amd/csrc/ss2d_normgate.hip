@@ -24,11 +24,7 @@ struct NormGateParams {
     float eps;
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+__device__ __forceinline__ float wave_sum(float v) { return lanes_sum<64>(v); }
 
 template <int K, typename IO>
 __global__ __launch_bounds__(256) void normgate_fwd_kernel(const NormGateParams p) {
