@@ -312,9 +312,10 @@ __global__ __launch_bounds__(256) void ln_head_fwd_kernel(const LNParams p, cons
     }
 }
 
-template <int NCP, typename TI, typename TO>
-__global__ __launch_bounds__(1024) void ln_head_bwd_kernel(const LNParams p, const HeadParams hp) {
-    constexpr int LW = 32, NWV = 16;
+// NWV waves per workgroup: 16 for up to 4 classes; 8 beyond, where 128 registers per lane would spill
+template <int NCP, int NWV, typename TI, typename TO>
+__global__ __launch_bounds__(NWV * 64) void ln_head_bwd_kernel(const LNParams p, const HeadParams hp) {
+    constexpr int LW = 32;
     __shared__ __attribute__((aligned(16))) float red[NWV * 2 * 256];
     const int lane = threadIdx.x & (LW - 1), half = (threadIdx.x & 63) >> 5;
     const long long wid = (long long)blockIdx.x * NWV + (threadIdx.x >> 6), nw = (long long)gridDim.x * NWV;
@@ -395,12 +396,14 @@ int launch_head(bool bwd, const LNParams &p, const HeadParams &hp, hipStream_t s
         else if (ncp == 10) hipLaunchKernelGGL((ln_head_fwd_kernel<10, TI, TO>), grid, block, 0, s, p, hp);
         else hipLaunchKernelGGL((ln_head_fwd_kernel<16, TI, TO>), grid, block, 0, s, p, hp);
     } else {
-        long long nwg = (p.rows + 1023) / 1024;    // 16 waves x 64 rows
-        if (nwg > 256) nwg = 256;
-        const dim3 grid((unsigned)nwg), block(1024);
-        if (ncp == 4) hipLaunchKernelGGL((ln_head_bwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
-        else if (ncp == 10) hipLaunchKernelGGL((ln_head_bwd_kernel<10, TI, TO>), grid, block, 0, s, p, hp);
-        else hipLaunchKernelGGL((ln_head_bwd_kernel<16, TI, TO>), grid, block, 0, s, p, hp);
+        const int nwv = ncp == 4 ? 16 : 8;
+        long long nwg = (p.rows + nwv * 64 - 1) / (nwv * 64);    // 64 rows per wave and trip
+        const long long cap = ncp == 4 ? 256 : 512;              // 4096 waves in all either way
+        if (nwg > cap) nwg = cap;
+        const dim3 grid((unsigned)nwg), block(nwv * 64);
+        if (ncp == 4) hipLaunchKernelGGL((ln_head_bwd_kernel<4, 16, TI, TO>), grid, block, 0, s, p, hp);
+        else if (ncp == 10) hipLaunchKernelGGL((ln_head_bwd_kernel<10, 8, TI, TO>), grid, block, 0, s, p, hp);
+        else hipLaunchKernelGGL((ln_head_bwd_kernel<16, 8, TI, TO>), grid, block, 0, s, p, hp);
     }
     return (int)hipGetLastError();
 }
