@@ -7,6 +7,8 @@
 """
 from __future__ import annotations
 
+import os as _os
+
 import torch
 import torch.nn.functional as F
 
@@ -83,7 +85,10 @@ def make_sgd(params, lr=0.01, tensor_lr_device=None):
     0-dim device tensor so that a HIP-graph-captured step (GraphedSupervisedStep) sees the poly-LR updates."""
     if tensor_lr_device is not None:
         return CapturableSGD(params, lr, momentum=0.9, weight_decay=1e-4, device=tensor_lr_device)
-    return torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4)
+    params = list(params)
+    # same update rule; on GPU parameters torch's fused implementation does it in one multi-tensor pass instead of three
+    fused = bool(params) and all(p.is_cuda for p in params) and not _os.environ.get("SS2D_NO_FUSED_SGD")
+    return torch.optim.SGD(params, lr=lr, momentum=0.9, weight_decay=1e-4, fused=fused)
 
 
 def set_lr(optimizer, lr: float):
