@@ -40,8 +40,9 @@ def main():
     ap.add_argument("--literal-directions", action="store_true",
                     help="A/B: run cross_scan / scan / cross_merge literally (4 materialised directions) instead of the fused-direction path")
     ap.add_argument("--graph", action="store_true",
-                    help="train mode, 1 GPU: capture the whole step in a HIP graph (experimental: refused unless "
-                         "SS2D_ALLOW_HIP_GRAPH=1, torch's reductions replay wrongly on this stack; not a number of record)")
+                    help="1 GPU.  infer: replay the forward from a HIP graph (checked against eager at capture).  train: "
+                         "whole-step capture, experimental: refused unless SS2D_ALLOW_HIP_GRAPH=1, torch's reductions "
+                         "replay wrongly on this stack; not a number of record")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -76,9 +77,16 @@ def main():
     if args.mode == "infer":
         net = nets[0].eval()
 
-        def step(it):
-            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
-                return net(images)
+        if args.graph and world == 1:      # forward-only capture: verified against eager inside GraphedForward
+            from mamba_unet_amd.train import GraphedForward
+            gfwd = GraphedForward(net, images, autocast_bf16=bf16)
+
+            def step(it):
+                return gfwd(gfwd.inp)
+        else:
+            def step(it):
+                with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+                    return net(images)
     elif args.mode == "train":
         net = wrap_ddp(nets[0].train(), local)
         if args.graph and world == 1:
@@ -131,7 +139,7 @@ def main():
             "config": {"workload": f"MambaUNet (VSSM tiny, depths 2-2-2-2, {n_params} params) {args.mode}, batch "
                                    f"{args.batch} per GPU, {args.size}x{args.size}, {args.classes} classes",
                        "parallelism": f"DDP x{world} (batch-sharded slices, RCCL gradient all-reduce)"},
-            "hip_graph": bool(args.graph and world == 1 and args.mode == "train"),
+            "hip_graph": bool(args.graph and world == 1 and args.mode in ("train", "infer")),
             "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "finite": finite, "valid": finite}))
     if dist is not None:
         dist.destroy_process_group()

@@ -405,3 +405,17 @@ def test_ln_unshuffle_head_fused(B, H, W, c, p, nc, dtype):
     assert rel_l2(xd.grad.float().cpu(), xr.grad) < tol
     assert rel_l2(ld.weight.grad.cpu(), lr.weight.grad) < ptol and rel_l2(ld.bias.grad.cpu(), lr.bias.grad) < ptol
     assert rel_l2(cd.weight.grad.cpu(), cr.weight.grad) < ptol
+
+
+def test_graphed_forward_matches_eager():
+    """Eval forward replayed from a HIP graph (batch-1 latency path) equals the eager forward bit for bit, also on a
+    new input copied into the static buffer."""
+    from mamba_unet_amd import MambaUnet
+    from mamba_unet_amd.train import GraphedForward
+    torch.manual_seed(3)
+    net = MambaUnet(img_size=64, num_classes=4).cuda().eval()
+    x0, x1 = torch.rand(1, 1, 64, 64, device="cuda"), torch.rand(1, 1, 64, 64, device="cuda")
+    g = GraphedForward(net, x0)
+    with torch.no_grad():
+        want = net(x1)
+    assert torch.equal(g(x1), want)
