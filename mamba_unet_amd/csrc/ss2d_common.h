@@ -6,6 +6,7 @@
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+#define SS2D_MAX_DEVICES 64   // per-device host-side caches (function attributes, symbol addresses)
 #define SS2D_LOG2E 1.4426950408889634f
 #define SS2D_LN2 0.6931471805599453f
 
@@ -144,6 +145,48 @@ __device__ __forceinline__ f4 load4m(const IO *__restrict__ row, int pos, int L,
     return r;
 }
 
+// 2 consecutive scan positions pos, pos+1 (pos even).  The address is clamped instead of the load being guarded (a
+// guarded load is sunk by the compiler into its branch with a full wait, which defeats prefetching); `ok` says
+// whether the value counts.  VEC needs L % 2 == 0 and a base pointer aligned to 2 elements.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 ld2(const float *p) { return *reinterpret_cast<const f2 *>(p); }
+__device__ __forceinline__ f2 ld2(const bf16 *p) { return __builtin_convertvector(*reinterpret_cast<const bf16x2 *>(p), f2); }
+__device__ __forceinline__ void st2(float *p, f2 v) { *reinterpret_cast<f2 *>(p) = v; }
+__device__ __forceinline__ void st2(bf16 *p, f2 v) { *reinterpret_cast<bf16x2 *>(p) = __builtin_convertvector(v, bf16x2); }
+template <bool VEC, typename IO>
+__device__ __forceinline__ f2 load2m_nomask(const IO *__restrict__ row, int pos, int L, bool rev) {
+    if (VEC) {
+        const int ps = pos < L ? pos : 0;
+        const f2 t = ld2(row + (unsigned)(rev ? L - 2 - ps : ps));
+        return rev ? f2{t.y, t.x} : t;
+    }
+    f2 r;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int ps = pos + e < L ? pos + e : 0;
+        r[e] = ld1(row + (unsigned)(rev ? L - 1 - ps : ps));
+    }
+    return r;
+}
+// A wave-uniform element offset pinned into scalar registers: `base + uniform_off(x) + lane_offset` then selects the
+// saddr form of global_load / global_store (SGPR base + 32-bit lane offset) instead of a 64-bit per-lane address that
+// the compiler keeps alive across a loop.  (Pinning the POINTER through integers would lose the address space and
+// turn every access into a flat_ one.)
+__device__ __forceinline__ size_t uniform_off(size_t v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((size_t)hi << 32) | lo;
+}
+template <bool VEC, typename IO>
+__device__ __forceinline__ void store2m(IO *__restrict__ row, int pos, int L, bool rev, f2 v) {
+    if (VEC) {
+        if (pos < L) st2(row + (unsigned)(rev ? L - 2 - pos : pos), rev ? f2{v.y, v.x} : v);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+            if (pos + e < L) st1(row + (unsigned)(rev ? L - 1 - pos - e : pos + e), v[e]);
+    }
+}
+
 // thread-local error string shared by the C-ABI entry points
 void ss2d_set_error(const char *fmt, ...);
 
@@ -196,4 +239,77 @@ __device__ __forceinline__ void wg_colsum2(float *red, f4 (&a)[K], f4 (&b)[K], i
         for (int w = 0; w < NWV; ++w) s += red[(w * 2 + which) * K * 256 + col];
         atomicAdd((which ? out_b : out_a) + col, s);
     }
+}
+
+// ---- raw buffer access (SGPR resource + 32-bit lane offset): the address of a wave-uniform row costs no VGPR, and the
+// hardware range check (offset >= num_records reads 0 / drops the store) replaces the tail masks of a ragged row.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, bytes, 0x00020000);   // raw, untyped dwords
+}
+__device__ __forceinline__ f2 bf16pair_to_f2(unsigned v) { return f2{__builtin_bit_cast(float, v << 16), __builtin_bit_cast(float, v & 0xffff0000u)}; }
+// 2 consecutive scan positions pos, pos+1 (pos even) of the row behind `rs` (num_records = row bytes); positions past
+// the row read 0.  VEC: L even, row base aligned to 2 elements.
+template <bool VEC, typename IO>
+__device__ __forceinline__ f2 buf_load2m(__amdgpu_buffer_rsrc_t rs, int pos, int L, bool rev) {
+    constexpr bool F32 = sizeof(IO) == 4;
+    if (VEC) {
+        const int idx = rev ? L - 2 - pos : pos;   // negative -> huge unsigned offset -> out of range -> 0
+        f2 t;
+        if (F32) t = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, idx * 4, 0, 0));
+        else t = bf16pair_to_f2(__builtin_amdgcn_raw_buffer_load_b32(rs, idx * 2, 0, 0));
+        return rev ? f2{t.y, t.x} : t;
+    }
+    f2 r;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int idx = rev ? L - 1 - pos - e : pos + e;
+        if (F32) r[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, idx * 4, 0, 0));
+        else r[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, idx * 2, 0, 0) << 16);
+    }
+    return r;
+}
+template <bool VEC, typename IO>
+__device__ __forceinline__ void buf_store2m(__amdgpu_buffer_rsrc_t rs, int pos, int L, bool rev, f2 v) {
+    constexpr bool F32 = sizeof(IO) == 4;
+    if (VEC) {
+        const int idx = rev ? L - 2 - pos : pos;
+        const f2 w = rev ? f2{v.y, v.x} : v;
+        if (F32) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), rs, idx * 4, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_convertvector(w, bf16x2)), rs, idx * 2, 0, 0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int idx = rev ? L - 1 - pos - e : pos + e;
+            const float ve = v[e];   // a copy: __builtin_bit_cast applied to the vector ELEMENT v[e] reads element 0 (hipcc 7.2)
+            if (F32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ve), rs, idx * 4, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)ve), rs, idx * 2, 0, 0);
+        }
+    }
+}
+// 4 consecutive scan positions pos..pos+3 (pos % 4 == 0) of row `row_elems`-th element on inside the block behind `rs`
+template <bool VEC, typename IO>
+__device__ __forceinline__ f4 buf_load4m(__amdgpu_buffer_rsrc_t rs, unsigned row_off, int pos, int L, bool rev) {
+    constexpr bool F32 = sizeof(IO) == 4;
+    f4 r;
+    if (VEC) {
+        const int idx = rev ? L - 4 - pos : pos;
+        const unsigned off = (pos < L) ? row_off + (unsigned)idx : 0xffffffffu / 8;   // past the row: out of range -> 0
+        if (F32) r = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rs, off * 4, 0, 0));
+        else {
+            const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off * 2, 0, 0);
+            const f2 a = bf16pair_to_f2(t.x), b = bf16pair_to_f2(t.y);
+            r = f4{a.x, a.y, b.x, b.y};
+        }
+        return rev ? f4{r.w, r.z, r.y, r.x} : r;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int idx = rev ? L - 1 - pos - e : pos + e;
+        const unsigned off = (pos + e < L) ? row_off + (unsigned)idx : 0xffffffffu / 8;
+        if (F32) r[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off * 4, 0, 0));
+        else r[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, off * 2, 0, 0) << 16);
+    }
+    return r;
 }

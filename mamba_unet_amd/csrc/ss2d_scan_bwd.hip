@@ -1,5 +1,7 @@
 // Selective scan backward for gfx950 (autograd half of `selective_scan_fn`,
 // /root/reference/code/networks/mamba_sys.py:436-442; forward semantics :62-144).
+// GENERAL path (any dstate <= 16, optional z gate); the SS2D call pattern (dstate 16, no z) is dispatched to the
+// state-row kernel of ss2d_scan_bwd_sr.hip.
 //
 // Same lane layout as the forward (ss2d_scan_fwd.hip): a wave = 4 channel rows x 16 lanes x 8 positions.
 // Chunks of 128 positions are walked from the END of the sequence to the start:
@@ -8,13 +10,14 @@
 //   * the adjoint recurrence  r_l = a_l * (dy_l*C_l + r_{l+1})  (r_l = a_l * dL/dh_l) is scanned the other
 //     way with row_shl DPP steps; the value leaving the chunk on the left is carried to the next
 //     (earlier) chunk through LDS;
-//   * dB/dC are sums over the channels of a group: every lane adds its products into a per-row LDS tile
-//     (ds_add_f32, conflict-free layout), the workgroup then adds the 4 row tiles and issues ONE global
+//   * dB/dC are sums over the channels of a group: the 4 rows of a wave are summed in registers with a
+//     v_permlane16/32_swap butterfly, every wave adds the result into its private LDS tile (plain
+//     read-modify-write, bank-swizzled), the workgroup then adds the wave tiles and issues ONE global
 //     float atomic per element and chunk;
 //   * dA/dD/ddelta_bias are reduced over lanes (DPP row sums), over chunks (LDS / registers) and
 //     over batch (global float atomics at the end).
 #include <cstdlib>
-#include "ss2d_common.h"
+#include "ss2d_scan.h"
 #include "../../include/ss2d.h"
 
 namespace {
@@ -23,75 +26,6 @@ constexpr int T = 8;
 constexpr int CHUNK = 128;
 constexpr int NP = 8;
 constexpr int ACC_WAVE_FLOATS = NP * 2 * 4 * 64;  // per wave: [np][mat][item pair][lane], rows already summed
-
-struct ScanBwdParams {
-    const void *u, *delta, *B, *C, *z, *dout;   // IO type (fp32 or bf16)
-    const float *A, *D, *bias, *ckpt;
-    void *du, *ddelta, *dz;                      // IO type
-    float *dA, *dB, *dC, *dD, *dbias;            // fp32 accumulators (atomics)
-    int batch, dim, L, N, G, dpg, nchunks, softplus, wgs_per_group, nwg, rounds, cb;
-    int Gu;              // u and dout have Gu groups per batch; scan group g uses group g / (G / Gu)
-    unsigned rev_mask;   // bit g: group g runs over its rows in reverse memory order
-    long long bc_stride; // elements between consecutive (batch, group) blocks of B and of C (N*L when dense); dB/dC are dense
-};
-
-#define SS2D_FSTEP(n)                                                                  \
-    "v_fmac_f32_dpp %0, %0, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
-    "v_fmac_f32_dpp %1, %1, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
-    "v_mul_f32_dpp %2, %2, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"          \
-    "v_mul_f32_dpp %3, %3, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf\n\t"
-#define SS2D_RSTEP(n)                                                                  \
-    "v_fmac_f32_dpp %0, %0, %2 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
-    "v_fmac_f32_dpp %1, %1, %3 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"         \
-    "v_mul_f32_dpp %2, %2, %2 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"          \
-    "v_mul_f32_dpp %3, %3, %3 row_shl:" #n " row_mask:0xf bank_mask:0xf\n\t"
-
-// inclusive prefix scan of (a, h) along the 16 lanes of a row: h_i <- h_i + a_i * h_{i-s}
-__device__ __forceinline__ void row_scan_fwd_pair(float &hx, float &hy, float &ax, float &ay) {
-    asm volatile("s_nop 1\n\t" SS2D_FSTEP(1) SS2D_FSTEP(2) SS2D_FSTEP(4)
-                 "v_fmac_f32_dpp %0, %0, %2 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %1, %1, %3 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 : "+v"(hx), "+v"(hy), "+v"(ax), "+v"(ay));
-}
-// inclusive suffix scan: r_i <- r_i + a_i * r_{i+s}
-__device__ __forceinline__ void row_scan_rev_pair(float &rx, float &ry, float &ax, float &ay) {
-    asm volatile("s_nop 1\n\t" SS2D_RSTEP(1) SS2D_RSTEP(2) SS2D_RSTEP(4)
-                 "v_fmac_f32_dpp %0, %0, %2 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f32_dpp %1, %1, %3 row_shl:8 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 1\n\t"
-                 : "+v"(rx), "+v"(ry), "+v"(ax), "+v"(ay));
-}
-// sum over the 16 lanes of a row; the total lands in lane 15 of the row.  Two values at once so that the DPP
-// read-after-write hazard of one chain is covered by the other; the shifted operand reads 0 outside the row
-// (bound_ctrl), and the add is fused into the DPP instruction (the compiler emits v_mov_dpp + v_add instead).
-__device__ __forceinline__ void row_sum2_to_lane15(float &x, float &y) {
-#define SS2D_ASTEP(n)                                                                              \
-    "v_add_f32_dpp %0, %0, %0 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
-    "v_add_f32_dpp %1, %1, %1 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
-    "s_nop 0\n\t"
-    asm volatile("s_nop 1\n\t" SS2D_ASTEP(1) SS2D_ASTEP(2) SS2D_ASTEP(4) SS2D_ASTEP(8) : "+v"(x), "+v"(y));
-#undef SS2D_ASTEP
-}
-
-// Sum four per-lane values over the 4 DPP rows of the wave: on return row r of the result holds the
-// total (over rows) of x_r.  v_permlane16_swap exchanges the odd rows of its first operand with the
-// even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the
-// second; each swap is followed by one add (1.5 VALU ops per value instead of an LDS float atomic,
-// which runs ~3 cycles PER LANE on gfx950).
-__device__ __forceinline__ void rows_reduce4x2(float &x0, float x1, float x2, float x3, float &y0, float y1, float y2, float y3) {
-    // two independent 4-value reductions in one block: fewer hazard nops (x0 / y0 receive the results)
-    asm volatile("s_nop 1\n\t"
-                 "v_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\t"
-                 "v_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7\n\t"
-                 "s_nop 0\n\t"
-                 "v_add_f32 %0, %0, %1\n\tv_add_f32 %2, %2, %3\n\tv_add_f32 %4, %4, %5\n\tv_add_f32 %6, %6, %7\n\t"
-                 "s_nop 1\n\t"
-                 "v_permlane32_swap_b32 %0, %2\n\tv_permlane32_swap_b32 %4, %6\n\t"
-                 "s_nop 0\n\t"
-                 "v_add_f32 %0, %0, %2\n\tv_add_f32 %4, %4, %6\n\t"
-                 : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
-}
 
 // DIRS: direction-aware build (rev_mask / u_groups honoured); false compiles the mirrored paths away
 template <int NW, bool HAS_Z, bool VEC4, typename IO, bool DIRS>
@@ -389,10 +323,17 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_kernel(const ScanBwdParams p
 template <int NW, bool HAS_Z, bool VEC4, typename IO, bool DIRS>
 int launch_one(const ScanBwdParams &p, size_t lds, hipStream_t s) {
     auto kern = scan_bwd_kernel<NW, HAS_Z, VEC4, IO, DIRS>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kern, dim3(p.nwg), dim3(NW * 64), lds, s, p);
-    return (int)hipGetLastError();
+    static size_t lds_set[SS2D_MAX_DEVICES] = {};   // per instantiation and device: the largest size already granted
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SS2D_MAX_DEVICES) dev = 0;
+    if (lds > lds_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        lds_set[dev] = lds;
+    }
+    ScanBwdParams pc = p;
+    void *args[] = {&pc};
+    return (int)hipLaunchKernel(reinterpret_cast<const void *>(kern), dim3(p.nwg), dim3(NW * 64), args, lds, s);
 }
 template <int NW, typename IO, bool DIRS>
 int launch_bwd(const ScanBwdParams &p, bool has_z, bool vec4, size_t lds, hipStream_t s) {
@@ -454,10 +395,8 @@ extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void 
         rounds = 3;
         while (rounds > 1 && units * ((p.dpg + per_round * rounds - 1) / (per_round * rounds)) < 192) --rounds;
     }
-    if (const char *e = getenv("SS2D_BWD_ROUNDS")) {  // tuning knob for experiments; 1..3
-        const int r = atoi(e);
-        if (r >= 1 && r <= 3) rounds = r;
-    }
+    static const int env_rounds = [] { const char *e = getenv("SS2D_BWD_ROUNDS"); return e ? atoi(e) : 0; }();  // tuning knob, read once
+    if (env_rounds >= 1 && env_rounds <= 3) rounds = env_rounds;
     p.rounds = rounds; p.cb = per_round * rounds;
     p.wgs_per_group = (p.dpg + p.cb - 1) / p.cb;
     const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
@@ -471,6 +410,13 @@ extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void 
                          (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
     const bool dirs = rev_mask != 0 || u_groups != ngroups || bc_bg_stride != bc_dense;
+    // the SS2D call pattern: 16 states, no gate -> state-row kernel (SS2D_BWD_KERNEL=general keeps the general one: A/B runs)
+    static const bool force_general = [] { const char *e = getenv("SS2D_BWD_KERNEL"); return e && e[0] == 'g'; }();
+    if (dstate == 16 && z == nullptr && !force_general && ((((uintptr_t)A | (uintptr_t)ckpt) & 15) == 0)) {
+        const int rc = ss2d_scan_bwd_sr_launch(dtype, p, vec4, dirs, s);
+        if (rc) ss2d_set_error("selective_scan_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return rc;
+    }
     int rc = dtype == SS2D_DTYPE_BF16
                  ? (dirs ? launch_bwd_nw<bf16, true>(nw, p, z != nullptr, vec4, lds, s) : launch_bwd_nw<bf16, false>(nw, p, z != nullptr, vec4, lds, s))
                  : (dirs ? launch_bwd_nw<float, true>(nw, p, z != nullptr, vec4, lds, s) : launch_bwd_nw<float, false>(nw, p, z != nullptr, vec4, lds, s));

@@ -1,0 +1,382 @@
+// Selective scan backward, "state-row" decomposition, for gfx950 -- the fast path of
+// ss2d_selective_scan_{,dir_}bwd for dstate == 16 without z (the only form Mamba-UNet issues,
+// /root/reference/code/networks/mamba_sys.py:436-442; forward semantics :62-144).
+//
+// A wavefront works on ONE (batch, channel) sequence at a time: its 4 DPP rows own 4 states each (2 packed pairs),
+// the 16 lanes of a row own 8 consecutive positions each, so a wave covers a 128-position chunk x 16 states, and
+// it walks its channels one after the other inside a chunk, the chunks from the end of the sequence to the start.
+//   * dB / dC are sums over the channels of a group: with the states on the rows and the channels in time, every
+//     lane simply keeps adding into 64 registers (an FMA instead of a multiply: free); once per chunk the 8 waves
+//     of the workgroup put their registers into LDS, add them up and send ONE global float atomic per element.
+//     (The channel-row layout of ss2d_scan_bwd.hip needs a cross-row butterfly and an LDS read-modify-write per
+//     value instead: a quarter of its instructions.)
+//   * du / ddelta are sums over the 16 states = over the 4 rows: one v_permlane swap butterfly per channel-chunk
+//     for 16 values, after which lane (row r, segment s) holds positions 8s+2r, 8s+2r+1 -- exactly the two positions
+//     it loaded, ran the softplus for and staged into the wave's private LDS strip at the start.
+//   * B / C of the chunk are staged once per workgroup in LDS (the tile aliases the flush area, which is idle then).
+//   * Work is dealt in (batch, channel) rows, not in (batch, group) units: every one of the 256 CUs gets the same
+//     number of rows (72 at config 2); a workgroup whose rows straddle a group boundary runs the parts one after
+//     the other.  One 512-thread workgroup per CU (LDS-bound on purpose), 2 waves per SIMD.
+#include <cstdlib>
+#include "ss2d_scan.h"
+#include "../../include/ss2d.h"
+
+namespace {
+
+constexpr int T = 8;
+constexpr int CHUNK = 128;
+constexpr int NW = 8;                       // waves per workgroup
+constexpr int CW_MAX = 12;                  // channels per wave and part
+constexpr int REC = 48;                     // per (wave, channel) record in LDS: 16 adjoint carries | 16 dA | 4 rows x {dD, dbias, -, -}
+constexpr int SLOT = 2 * 16 * CHUNK;        // floats per wave in the flush area: [dB|dC][state][position]
+constexpr int STG = 3 * CHUNK;              // per wave: softplus(delta), delta*u, dout of the current channel-chunk
+constexpr int LDS_FLOATS = NW * SLOT + NW * STG + NW * CW_MAX * REC;
+static_assert(LDS_FLOATS * 4 <= 160 * 1024, "one workgroup per CU");
+static_assert(CHUNK == SS2D_SCAN_CHUNK, "checkpoint spacing is part of the ABI");
+
+template <bool VEC, typename IO, bool DIRS>
+__global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParams p) {
+    extern __shared__ __align__(16) float smem[];
+    float *slots = smem;                                        // [NW][SLOT]; slot 0 doubles as the B/C tile
+    f4 *tile = reinterpret_cast<f4 *>(smem);                   // [B|C][pair][item pair][seg] f4, as in ss2d_scan_fwd.hip
+    const int tid = threadIdx.x, lane = tid & 63, row = lane >> 4, seg = lane & 15;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float *st = smem + NW * SLOT + wave * STG;
+    float *recw = smem + NW * SLOT + NW * STG + wave * (CW_MAX * REC);          // this wave's channel records
+    float *slot = slots + wave * SLOT;
+
+    const int L = p.L, nchunks = p.nchunks;
+    const long long total = (long long)p.batch * p.dim;
+    const long long lo = (long long)blockIdx.x * p.rows_per_wg;
+    const long long hi = lo + p.rows_per_wg < total ? lo + p.rows_per_wg : total;
+
+    for (long long part_lo = lo; part_lo < hi;) {
+        // ---- one part = the rows of this workgroup that belong to one (batch, group)
+        const int bg = (int)(part_lo / p.dpg);
+        const int b = bg / p.G, g = bg - b * p.G;
+        long long part_hi = (long long)(bg + 1) * p.dpg;
+        if (part_hi > hi) part_hi = hi;
+        const int n = (int)(part_hi - part_lo);
+        const int cw = (n + NW - 1) / NW;                        // <= CW_MAX (host: rows_per_wg <= NW * CW_MAX)
+        const int k0 = wave * cw;
+        int nmine = n - k0;
+        nmine = nmine < 0 ? 0 : (nmine > cw ? cw : nmine);
+        const int klast = nmine > 0 ? nmine - 1 : 0;
+        const size_t r0 = (size_t)(part_lo + (nmine > 0 ? k0 : 0));   // (batch, channel) row of this wave's first channel
+        const int cin0 = (int)(r0 - (size_t)bg * p.dpg);
+        const int cdim0 = g * p.dpg + cin0;
+        const bool rev = DIRS && ((p.rev_mask >> g) & 1u);
+        const int ug = DIRS ? g / (p.G / p.Gu) : g;
+        const size_t bcs = DIRS ? (size_t)p.bc_stride : 16 * (size_t)L;
+        const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const IO *>(p.B) + (size_t)bg * bcs, 16u * L * sizeof(IO));
+        const __amdgpu_buffer_rsrc_t rsC = make_rsrc(static_cast<const IO *>(p.C) + (size_t)bg * bcs, 16u * L * sizeof(IO));
+        float *__restrict__ dBg = p.dB + (size_t)bg * 16 * (size_t)L;
+        float *__restrict__ dCg = p.dC + (size_t)bg * 16 * (size_t)L;
+        const size_t urow0 = DIRS ? ((size_t)(b * p.Gu + ug) * p.dpg + cin0) : r0;   // row of u / dout
+        // bias / D are read-only for the whole launch: constant address space -> scalar loads (no VGPR, no vmcnt slot)
+        typedef const float __attribute__((address_space(4))) *cfp;
+        const cfp biasp = (cfp)(uintptr_t)(p.bias ? p.bias : p.A), Dp = (cfp)(uintptr_t)(p.D ? p.D : p.A);   // always a valid address
+        const bool has_bias = p.bias != nullptr, has_D = p.D != nullptr;
+        const unsigned rowbytes = (unsigned)L * sizeof(IO);
+
+        for (int i = lane; i < CW_MAX * REC; i += 64) recw[i] = 0.0f;
+
+        // Everything that comes from memory is requested one step ahead and never under a branch (a load under a
+        // branch makes the compiler wait for every outstanding load at the join):
+        //   * u / delta / dout of channel k+1 at the top of channel k, its A row / checkpoint / bias / D between the two
+        //     state pairs of channel k; behind the last channel of a chunk the first channel of the NEXT chunk;
+        //   * the B / C tile of the next chunk before the flush of this one.
+        // Rows are addressed through buffer resources: a position outside the row reads 0 and drops the store.
+        const int tm = tid >> 8, tit = tid & 255, tnp = tit >> 5, tq4 = tit & 31;   // this thread's tile item
+        const int tj0 = (tq4 & 1) * 2, tsg = tq4 >> 1;
+        auto tile_load = [&](int chunk_, f4 &lo4, f4 &hi4) {
+            const int pos = chunk_ * CHUNK + tq4 * 4;
+            const __amdgpu_buffer_rsrc_t rs = tm ? rsC : rsB;
+            lo4 = buf_load4m<VEC, IO>(rs, (unsigned)(2 * tnp) * L, pos, L, rev);
+            hi4 = buf_load4m<VEC, IO>(rs, (unsigned)(2 * tnp + 1) * L, pos, L, rev);
+        };
+        f2 nu, nd, ny;
+        f4 nAv, nck;
+        float nbias, nD;
+        auto input_load = [&](int k_, int chunk_) {
+            const int ps_ = chunk_ * CHUNK + 8 * seg + 2 * row;
+            nu = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.u) + (urow0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
+            nd = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.delta) + (r0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
+            ny = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.dout) + (urow0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
+        };
+        auto param_load = [&](int k_, int chunk_) {
+            const int c_ = cdim0 + k_;
+            nAv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.A + (size_t)c_ * 16, 64), 16 * row, 0, 0));
+            nck = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.ckpt + ((r0 + k_) * nchunks + chunk_) * 16, 64), 16 * row, 0, 0));
+            nbias = biasp[c_];
+            nD = Dp[c_];
+        };
+        f4 tlo, thi;
+        tile_load(nchunks - 1, tlo, thi);
+        input_load(0, nchunks - 1);
+        param_load(0, nchunks - 1);
+
+        for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
+            const int base = chunk * CHUNK;
+            const int chunk_next = chunk > 0 ? chunk - 1 : 0;
+            __syncthreads();   // the previous flush has read the slots: slot 0 may become the tile again
+            tile[tm * 512 + (tnp * 4 + tj0) * 16 + tsg] = f4{tlo.x, thi.x, tlo.y, thi.y};
+            tile[tm * 512 + (tnp * 4 + tj0 + 1) * 16 + tsg] = f4{tlo.z, thi.z, tlo.w, thi.w};
+            __syncthreads();
+
+            f2 accB[2][T], accC[2][T];
+#pragma unroll
+            for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                for (int t = 0; t < T; ++t) { accB[pi][t] = f2{0.0f, 0.0f}; accC[pi][t] = f2{0.0f, 0.0f}; }
+
+            const int ps = base + 8 * seg + 2 * row;             // the two positions this lane stages and finishes
+            const bool ok0 = ps < L, ok1 = ps + 1 < L;
+            const int sto = 8 * seg + 2 * row, sta = 8 * seg, stb = 8 * seg + 4;
+            for (int k = 0; k < nmine; ++k) {
+                const bool lastk = k == klast;
+                const int kn = lastk ? 0 : k + 1, chn = lastk ? chunk_next : chunk;
+                const f2 cu = nu, cd = nd, cy = ny;
+                const f4 Av = nAv, ck = nck;
+                const float bias = has_bias ? nbias : 0.0f, Dc = has_D ? nD : 0.0f;
+                input_load(kn, chn);
+                // ---- this lane's two positions: softplus, delta*u; shared with the other rows through LDS
+                float x0 = cd.x + bias, x1 = cd.y + bias, sg0 = 1.0f, sg1 = 1.0f;
+                if (p.softplus) { x0 = softplus_sig<true>(x0, sg0); x1 = softplus_sig<true>(x1, sg1); }
+                const float dt0 = ok0 ? x0 : 0.0f, dt1 = ok1 ? x1 : 0.0f;   // positions past L are the identity
+                const float u0 = cu.x, u1 = cu.y, dy0 = cy.x, dy1 = cy.y;   // zero past L (buffer range check)
+                *reinterpret_cast<f2 *>(st + sto) = f2{dt0, dt1};
+                *reinterpret_cast<f2 *>(st + CHUNK + sto) = f2{dt0 * u0, dt1 * u1};
+                *reinterpret_cast<f2 *>(st + 2 * CHUNK + sto) = f2{dy0, dy1};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                f2 dtp[4], dup[4], dyp[4];                            // pairs of neighbouring positions (see pk_*_sel)
+                {
+                    const f4 a0 = *reinterpret_cast<const f4 *>(st + sta), a1 = *reinterpret_cast<const f4 *>(st + stb);
+                    const f4 b0 = *reinterpret_cast<const f4 *>(st + CHUNK + sta), b1 = *reinterpret_cast<const f4 *>(st + CHUNK + stb);
+                    const f4 c0 = *reinterpret_cast<const f4 *>(st + 2 * CHUNK + sta), c1 = *reinterpret_cast<const f4 *>(st + 2 * CHUNK + stb);
+                    dtp[0] = f2{a0.x, a0.y}; dtp[1] = f2{a0.z, a0.w}; dtp[2] = f2{a1.x, a1.y}; dtp[3] = f2{a1.z, a1.w};
+                    dup[0] = f2{b0.x, b0.y}; dup[1] = f2{b0.z, b0.w}; dup[2] = f2{b1.x, b1.y}; dup[3] = f2{b1.z, b1.w};
+                    dyp[0] = f2{c0.x, c0.y}; dyp[1] = f2{c0.z, c0.w}; dyp[2] = f2{c1.x, c1.y}; dyp[3] = f2{c1.z, c1.w};
+                }
+                float *rec = recw + k * REC + 4 * row;                    // + 0: carries, + 16: dA, + 32: dD / dbias of this row
+                const f4 rcv = *reinterpret_cast<const f4 *>(rec);       // adjoint entering from the right
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                float S = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) S += dtp[j].x + dtp[j].y;
+
+                float ddt[T], ddu[T];                                   // sums over this row's 4 states
+                f2 dAp[2], rleft[2];
+#pragma unroll
+                for (int t = 0; t < T; ++t) { ddt[t] = 0.0f; ddu[t] = 0.0f; }
+
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi) {
+                    const int np = 2 * row + pi;
+                    const f4 *__restrict__ tB = tile + (np * 4) * 16 + seg, *__restrict__ tC = tB + 512;
+                    const f2 A2 = f2{Av[2 * pi], Av[2 * pi + 1]} * SS2D_LOG2E;
+                    const f2 hin = f2{ck[2 * pi], ck[2 * pi + 1]};
+                    const f2 rcar = f2{rcv[2 * pi], rcv[2 * pi + 1]};
+                    f2 a[T], h[T];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { a[2 * j] = exp2_2(pk_mul_lo(dtp[j], A2)); a[2 * j + 1] = exp2_2(pk_mul_hi(dtp[j], A2)); }
+                    const f2 at = exp2_2(splat2(S) * A2);
+                    f2 hstart;
+                    f4 Cq[4];
+                    {   // ---- forward states of the chunk: lane-local pass, row scan, true pass
+                        f2 bb[T];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const f4 Bq = tB[j * 16];
+                            bb[2 * j] = pk_mul_lo(dup[j], f2{Bq.x, Bq.y});
+                            bb[2 * j + 1] = pk_mul_hi(dup[j], f2{Bq.z, Bq.w});
+                        }
+                        f2 hl = f2{seg == 0 ? hin.x : 0.0f, seg == 0 ? hin.y : 0.0f};
+#pragma unroll
+                        for (int t = 0; t < T; ++t) hl = fma2(a[t], hl, bb[t]);
+                        float hx = hl.x, hy = hl.y, ax = at.x, ay = at.y;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) Cq[j] = tC[j * 16];   // requested here: they arrive behind the row scan
+                        row_scan_fwd_pair(hx, hy, ax, ay);
+                        hstart.x = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(hin.x, hx);
+                        hstart.y = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(hin.y, hy);
+                        f2 hh = hstart;
+#pragma unroll
+                        for (int t = 0; t < T; ++t) { hh = fma2(a[t], hh, bb[t]); h[t] = hh; }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- adjoint r_l = a_l * (dy_l * C_l + r_{l+1}): lane-local suffix pass, row scan, true pass
+                    f2 rr;
+                    f4 Bn, Cn;
+                    {
+                        f2 rl = f2{seg == 15 ? rcar.x : 0.0f, seg == 15 ? rcar.y : 0.0f};
+#pragma unroll
+                        for (int j = 3; j >= 0; --j) {
+                            rl = a[2 * j + 1] * pk_fma_hi(dyp[j], f2{Cq[j].z, Cq[j].w}, rl);
+                            rl = a[2 * j] * pk_fma_lo(dyp[j], f2{Cq[j].x, Cq[j].y}, rl);
+                        }
+                        float rx = rl.x, ry = rl.y, ax = at.x, ay = at.y;
+                        Bn = tB[3 * 16]; Cn = tC[3 * 16];                 // first operands of the true pass, behind the row scan
+                        row_scan_rev_pair(rx, ry, ax, ay);
+                        rr.x = dpp_mov<DPP_ROW_SHL(1), 0xf, false>(rcar.x, rx);
+                        rr.y = dpp_mov<DPP_ROW_SHL(1), 0xf, false>(rcar.y, ry);
+                    }
+                    if (pi == 0) param_load(kn, chn);   // in flight during pair 1
+                    __builtin_amdgcn_sched_barrier(0);
+                    f2 dAacc = f2{0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 3; j >= 0; --j) {
+                        // B and C of the pair are re-read (keeping them alive costs 32 registers), one item pair ahead
+                        const f4 Bq = Bn, Cj = Cn;
+                        if (j > 0) { Bn = tB[(j - 1) * 16]; Cn = tC[(j - 1) * 16]; }
+                        {   // t = 2j + 1
+                            const int t = 2 * j + 1;
+                            const f2 Bt = f2{Bq.z, Bq.w}, Ct = f2{Cj.z, Cj.w};
+                            const f2 dh = pk_fma_hi(dyp[j], Ct, rr);             // dL/dh_t
+                            rr = a[t] * dh;                                       // a_t * dL/dh_t, flows to t-1
+                            pk_fmac_sel<1>(accC[pi][t], dyp[j], h[t]);
+                            pk_fmac_sel<1>(accB[pi][t], dup[j], dh);
+                            ddu[t] = fmaf(dh.x, Bt.x, fmaf(dh.y, Bt.y, ddu[t]));
+                            const f2 w = rr * h[t - 1];                           // dL/da_t * a_t
+                            ddt[t] = fmaf(w.x, A2.x, fmaf(w.y, A2.y, ddt[t]));   // log2 units; scaled by ln2 below
+                            dAacc = fma2(w, splat2(dtp[j].y), dAacc);
+                        }
+                        {   // t = 2j
+                            const int t = 2 * j;
+                            const f2 Bt = f2{Bq.x, Bq.y}, Ct = f2{Cj.x, Cj.y};
+                            const f2 dh = pk_fma_lo(dyp[j], Ct, rr);
+                            rr = a[t] * dh;
+                            pk_fmac_sel<0>(accC[pi][t], dyp[j], h[t]);
+                            pk_fmac_sel<0>(accB[pi][t], dup[j], dh);
+                            ddu[t] = fmaf(dh.x, Bt.x, fmaf(dh.y, Bt.y, ddu[t]));
+                            const f2 hp = (j > 0) ? h[t - 1] : hstart;
+                            const f2 w = rr * hp;
+                            ddt[t] = fmaf(w.x, A2.x, fmaf(w.y, A2.y, ddt[t]));
+                            dAacc = fma2(w, splat2(dtp[j].x), dAacc);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    dAp[pi] = dAacc;
+                    rleft[pi] = rr;                                           // lane 0: adjoint leaving the chunk on the left
+                }
+                if (seg == 0) *reinterpret_cast<f4 *>(rec) = f4{rleft[0].x, rleft[0].y, rleft[1].x, rleft[1].y};
+                {   // dA: row sums, accumulated over the chunks in LDS (4 lanes per instruction: the LDS float atomic is cheap here)
+                    float s0 = dAp[0].x, s1 = dAp[0].y, s2 = dAp[1].x, s3 = dAp[1].y;
+                    row_sum2_to_lane15(s0, s1);
+                    row_sum2_to_lane15(s2, s3);
+                    if (seg == 15) {
+                        atomicAdd(rec + 16, s0); atomicAdd(rec + 17, s1); atomicAdd(rec + 18, s2); atomicAdd(rec + 19, s3);
+                    }
+                }
+                // ---- sums over the 16 states = over the rows; row r ends up with positions 2r, 2r+1 of every segment
+                float e0 = ddu[0], e1 = ddu[2], e2 = ddu[4], e3 = ddu[6], o0 = ddu[1], o1 = ddu[3], o2 = ddu[5], o3 = ddu[7];
+                rows_reduce4x2(e0, e1, e2, e3, o0, o1, o2, o3);
+                float f0 = ddt[0], f1 = ddt[2], f2_ = ddt[4], f3 = ddt[6], g0 = ddt[1], g1 = ddt[3], g2 = ddt[5], g3 = ddt[7];
+                rows_reduce4x2(f0, f1, f2_, f3, g0, g1, g2, g3);
+                const f2 dtq = *reinterpret_cast<const f2 *>(st + sto), dyq = *reinterpret_cast<const f2 *>(st + 2 * CHUNK + sto);   // re-read: 4 registers
+                float ddta = f0 * SS2D_LN2 + e0 * u0, ddtb = g0 * SS2D_LN2 + o0 * u1;
+                if (p.softplus) { ddta *= sg0; ddtb *= sg1; }
+                ddta = ok0 ? ddta : 0.0f;
+                ddtb = ok1 ? ddtb : 0.0f;
+                buf_store2m<VEC, IO>(make_rsrc(static_cast<IO *>(p.du) + (r0 + k) * (size_t)L, rowbytes), ps, L, rev,
+                                     f2{e0 * dtq.x + dyq.x * Dc, o0 * dtq.y + dyq.y * Dc});
+                buf_store2m<VEC, IO>(make_rsrc(static_cast<IO *>(p.ddelta) + (r0 + k) * (size_t)L, rowbytes), ps, L, rev, f2{ddta, ddtb});
+                float sD = dyq.x * u0 + dyq.y * u1, sb = ddta + ddtb;
+                row_sum2_to_lane15(sD, sb);
+                if (seg == 15) { atomicAdd(rec + 32, sD); atomicAdd(rec + 33, sb); }
+            }
+            tile_load(chunk_next, tlo, thi);   // arrives during the flush
+
+            __syncthreads();   // every wave is done with the tile
+            // ---- this wave's dB / dC sums -> its slot, [matrix][state][position], halves swizzled against bank conflicts
+            {
+                const int sw = ((seg >> 2) & 1) << 2;
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int o = (4 * row + 2 * pi + s) * CHUNK + 8 * seg;
+                        *reinterpret_cast<f4 *>(slot + (o ^ sw)) = f4{accB[pi][0][s], accB[pi][1][s], accB[pi][2][s], accB[pi][3][s]};
+                        *reinterpret_cast<f4 *>(slot + ((o + 4) ^ sw)) = f4{accB[pi][4][s], accB[pi][5][s], accB[pi][6][s], accB[pi][7][s]};
+                        *reinterpret_cast<f4 *>(slot + 2048 + (o ^ sw)) = f4{accC[pi][0][s], accC[pi][1][s], accC[pi][2][s], accC[pi][3][s]};
+                        *reinterpret_cast<f4 *>(slot + 2048 + ((o + 4) ^ sw)) = f4{accC[pi][4][s], accC[pi][5][s], accC[pi][6][s], accC[pi][7][s]};
+                    }
+            }
+            __syncthreads();
+            // ---- add the NW slots; one global atomic per element, 64 consecutive positions per wave instruction
+#pragma unroll
+            for (int e = 0; e < SLOT / (NW * 64); ++e) {
+                const int idx = e * (NW * 64) + tid;
+                const int phys = idx ^ (((idx >> 5) & 1) << 2);
+                float v = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += slots[w * SLOT + phys];
+                const int mat = idx >> 11, nn = (idx >> 7) & 15, pos = base + (idx & 127);
+                if (pos < L) atomicAdd((mat ? dCg : dBg) + (size_t)nn * L + (rev ? L - 1 - pos : pos), v);
+            }
+        }
+        // ---- dA / dD / ddelta_bias of this wave's channels: sums over the batch -> global atomics
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int i = lane; i < nmine * 16; i += 64) atomicAdd(p.dA + (size_t)cdim0 * 16 + i, recw[(i >> 4) * REC + 16 + (i & 15)]);
+        if (lane < nmine) {
+            const float *q = recw + lane * REC + 32;
+            if (p.dD) atomicAdd(p.dD + cdim0 + lane, (q[0] + q[4]) + (q[8] + q[12]));
+            if (p.dbias) atomicAdd(p.dbias + cdim0 + lane, (q[1] + q[5]) + (q[9] + q[13]));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        part_lo = part_hi;
+    }
+}
+
+template <bool VEC, typename IO, bool DIRS>
+int launch_sr(const ScanBwdParams &p, int nwg, hipStream_t s) {
+    auto kern = scan_bwd_sr_kernel<VEC, IO, DIRS>;
+    static bool attr_set[SS2D_MAX_DEVICES] = {};   // per instantiation and device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SS2D_MAX_DEVICES) dev = 0;
+    if (!attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * 4);
+        if (e != hipSuccess) return (int)e;
+        attr_set[dev] = true;
+    }
+    ScanBwdParams pc = p;
+    void *args[] = {&pc};
+    return (int)hipLaunchKernel(reinterpret_cast<const void *>(kern), dim3(nwg), dim3(NW * 64), args, LDS_FLOATS * 4, s);
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
+}  // namespace
+
+int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, hipStream_t s) {
+    // rows per workgroup: the same number for every CU, several resident rounds when there are more than
+    // NW * CW_MAX rows per CU
+    const long long total = (long long)p.batch * p.dim;
+    const int ncu = num_cus();
+    long long per = (total + ncu - 1) / ncu;
+    for (int m = 2; per > NW * CW_MAX; ++m) per = (total + (long long)ncu * m - 1) / ((long long)ncu * m);
+    if (per < NW) per = NW;
+    p.rows_per_wg = (int)per;
+    const long long nwg = (total + per - 1) / per;
+    if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidConfiguration;
+    if (dtype == SS2D_DTYPE_BF16) {
+        if (dirs) return vec4 ? launch_sr<true, bf16, true>(p, (int)nwg, s) : launch_sr<false, bf16, true>(p, (int)nwg, s);
+        return vec4 ? launch_sr<true, bf16, false>(p, (int)nwg, s) : launch_sr<false, bf16, false>(p, (int)nwg, s);
+    }
+    if (dirs) return vec4 ? launch_sr<true, float, true>(p, (int)nwg, s) : launch_sr<false, float, true>(p, (int)nwg, s);
+    return vec4 ? launch_sr<true, float, false>(p, (int)nwg, s) : launch_sr<false, float, false>(p, (int)nwg, s);
+}
