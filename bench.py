@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--atomic-dbc", action="store_true", help="dB/dC through float atomics (no workspace): the round-1 form")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -93,10 +94,17 @@ def main():
     out = torch.empty_like(inp["u"])
     ckpt = torch.empty(lib.ss2d_scan_ckpt_bytes(BATCH, KD, L, N) // 4, device=dev)
     du, ddelta = torch.empty_like(out), torch.empty_like(out)
-    # one flat buffer for the atomically accumulated gradients -> a single memset per step
-    sizes = [KD * N, BATCH * K * N * L, BATCH * K * N * L, KD, KD]
+    # one flat buffer for the atomically accumulated gradients -> a single memset per step.  With the workspace the
+    # library writes dB / dC itself (partial tiles + one reduction pass), so only dA, dD, dbias are zero-filled.
+    ws_bytes = 0 if args.atomic_dbc else int(lib.ss2d_scan_bwd_workspace_bytes(BATCH, KD, L, N, K))
+    ws = torch.empty(ws_bytes // 4, device=dev) if ws_bytes else None
+    sizes = [KD * N, KD, KD] + ([] if ws_bytes else [BATCH * K * N * L, BATCH * K * N * L])
     flat = torch.empty(sum(sizes), device=dev)
-    dA, dB, dC, dD, dbias = torch.split(flat, sizes)
+    if ws_bytes:
+        dA, dD, dbias = torch.split(flat, sizes)
+        dB, dC = torch.empty(BATCH * K * N * L, device=dev), torch.empty(BATCH * K * N * L, device=dev)
+    else:
+        dA, dD, dbias, dB, dC = torch.split(flat, sizes)
     P = _lib.ptr
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -106,10 +114,10 @@ def main():
                                                BATCH, KD, L, N, K, 1, stream), "fwd")
 
     def bwd():
-        _lib.check(lib.ss2d_selective_scan_bwd(0, P(inp["u"]), P(inp["delta"]), P(inp["A"]), P(inp["B"]), P(inp["C"]),
-                                               P(inp["D"]), None, P(inp["delta_bias"]), P(dout), P(ckpt), P(du),
-                                               P(ddelta), P(dA), P(dB), P(dC), P(dD), None, P(dbias),
-                                               BATCH, KD, L, N, K, 1, stream), "bwd")
+        _lib.check(lib.ss2d_selective_scan_dir_bwd_ws(0, P(inp["u"]), P(inp["delta"]), P(inp["A"]), P(inp["B"]), P(inp["C"]),
+                                                      P(inp["D"]), None, P(inp["delta_bias"]), P(dout), P(ckpt), P(du),
+                                                      P(ddelta), P(dA), P(dB), P(dC), P(dD), None, P(dbias),
+                                                      BATCH, KD, L, N, K, 1, K, 0, 0, P(ws), ws_bytes, stream), "bwd")
 
     def step(ev=None):
         if ev:

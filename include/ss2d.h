@@ -88,6 +88,21 @@ int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void *delta, con
                                 int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask,
                                 long long bc_bg_stride, void *stream);
 
+/* The same backward with a caller-provided workspace for the partial dB / dC sums of the workgroups (the sums over
+ * the channels of a group, mamba_sys.py:425-426 share B / C across a direction's d_inner channels):
+ *   workspace : >= ss2d_scan_bwd_workspace_bytes(...) bytes of device memory, 16-byte aligned, contents irrelevant;
+ *               with it (and dstate == 16, z == NULL, L % 4 == 0) dB / dC are WRITTEN (plain stores + one reduction
+ *               pass: deterministic, need no zero-fill); NULL / too small / other shapes = float atomics as above.
+ *   dA, dD, ddelta_bias are accumulated with atomics either way (caller zero-fills).
+ * ss2d_scan_bwd_workspace_bytes returns 0 when no workspace would be used. */
+size_t ss2d_scan_bwd_workspace_bytes(int batch, int dim, int L, int dstate, int ngroups);
+int ss2d_selective_scan_dir_bwd_ws(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                   const void *C, const float *D, const void *z, const float *delta_bias,
+                                   const void *dout, const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
+                                   float *dC, float *dD, void *dz, float *ddelta_bias, int batch, int dim, int L,
+                                   int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask,
+                                   long long bc_bg_stride, void *workspace, size_t workspace_bytes, void *stream);
+
 /* CrossScan (mamba_sys.py:403-404): x (B, D, H, W) -> xs (B, 4, D, H*W); _bwd is its adjoint
  * (sums the four directions back into dx). */
 int ss2d_cross_scan_fwd(int dtype, const void *x, void *xs, int B, int D, int H, int W, void *stream);

@@ -13,10 +13,14 @@ struct ScanBwdParams {
     unsigned rev_mask;   // bit g: group g runs over its rows in reverse memory order
     long long bc_stride; // elements between consecutive (batch, group) blocks of B and of C (N*L when dense); dB/dC are dense
     int rows_per_wg;     // state-row kernel: (batch, channel) rows per workgroup
+    float *ws;           // state-row kernel: partial dB/dC tiles (one per workgroup and (batch, group) it touches), or null = atomics
 };
 
 // The state-row backward (ss2d_scan_bwd_sr.hip): dstate == 16, no z.  Returns a hipError_t / 0.
-int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, hipStream_t s);
+// ws (nullable): ss2d_scan_bwd_sr_ws_bytes() bytes; with it dB/dC are written with plain stores + one reduction
+// kernel (deterministic, no zero-fill needed), without it they are accumulated with float atomics.
+int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, float *ws, size_t ws_bytes, hipStream_t s);
+size_t ss2d_scan_bwd_sr_ws_bytes(int batch, int dim, int L, int ngroups);
 
 // Packed fp32 math with one operand broadcast from HALF of a register pair (op_sel), so that `splat(x) * v` needs no
 // v_mov to build the splat: `s` is a pair of neighbouring values (two consecutive positions as they come out of an

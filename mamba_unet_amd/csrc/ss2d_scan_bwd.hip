@@ -365,6 +365,23 @@ extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void 
                                            float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
                                            int dim, int L, int dstate, int ngroups, int delta_softplus, int u_groups,
                                            unsigned rev_mask, long long bc_bg_stride, void *stream) {
+    return ss2d_selective_scan_dir_bwd_ws(dtype, u, delta, A, B, C, D, z, delta_bias, dout, ckpt, du, ddelta, dA, dB, dC, dD, dz,
+                                          ddelta_bias, batch, dim, L, dstate, ngroups, delta_softplus, u_groups, rev_mask,
+                                          bc_bg_stride, nullptr, 0, stream);
+}
+
+extern "C" size_t ss2d_scan_bwd_workspace_bytes(int batch, int dim, int L, int dstate, int ngroups) {
+    if (batch <= 0 || dim <= 0 || L <= 0 || ngroups <= 0 || dstate != 16 || L % 4) return 0;   // only the 16-state kernel uses one
+    return ss2d_scan_bwd_sr_ws_bytes(batch, dim, L, ngroups);
+}
+
+extern "C" int ss2d_selective_scan_dir_bwd_ws(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                              const void *C, const float *D, const void *z, const float *delta_bias,
+                                              const void *dout, const float *ckpt, void *du, void *ddelta, float *dA,
+                                              float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
+                                              int dim, int L, int dstate, int ngroups, int delta_softplus, int u_groups,
+                                              unsigned rev_mask, long long bc_bg_stride, void *workspace,
+                                              size_t workspace_bytes, void *stream) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_bwd: unknown dtype %d", dtype); return -1; }
     if (!u || !delta || !A || !B || !C || !dout || !ckpt || !du || !ddelta || !dA || !dB || !dC) {
         ss2d_set_error("selective_scan_bwd: null required pointer"); return -2; }
@@ -413,7 +430,7 @@ extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void 
     // the SS2D call pattern: 16 states, no gate -> state-row kernel (SS2D_BWD_KERNEL=general keeps the general one: A/B runs)
     static const bool force_general = [] { const char *e = getenv("SS2D_BWD_KERNEL"); return e && e[0] == 'g'; }();
     if (dstate == 16 && z == nullptr && !force_general && ((((uintptr_t)A | (uintptr_t)ckpt) & 15) == 0)) {
-        const int rc = ss2d_scan_bwd_sr_launch(dtype, p, vec4, dirs, s);
+        const int rc = ss2d_scan_bwd_sr_launch(dtype, p, vec4, dirs, static_cast<float *>(workspace), workspace_bytes, s);
         if (rc) ss2d_set_error("selective_scan_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
         return rc;
     }

@@ -34,7 +34,9 @@ constexpr int LDS_FLOATS = NW * SLOT + NW * STG + NW * CW_MAX * REC;
 static_assert(LDS_FLOATS * 4 <= 160 * 1024, "one workgroup per CU");
 static_assert(CHUNK == SS2D_SCAN_CHUNK, "checkpoint spacing is part of the ABI");
 
-template <bool VEC, typename IO, bool DIRS>
+// WS: dB/dC partial tiles go to the workspace with plain stores (slot = workgroup + (batch, group) index: unique,
+// and consecutive for the workgroups that share a (batch, group)); otherwise float atomics on dB/dC.
+template <bool VEC, typename IO, bool DIRS, bool WS>
 __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParams p) {
     extern __shared__ __align__(16) float smem[];
     float *slots = smem;                                        // [NW][SLOT]; slot 0 doubles as the B/C tile
@@ -70,8 +72,8 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
         const size_t bcs = DIRS ? (size_t)p.bc_stride : 16 * (size_t)L;
         const __amdgpu_buffer_rsrc_t rsB = make_rsrc(static_cast<const IO *>(p.B) + (size_t)bg * bcs, 16u * L * sizeof(IO));
         const __amdgpu_buffer_rsrc_t rsC = make_rsrc(static_cast<const IO *>(p.C) + (size_t)bg * bcs, 16u * L * sizeof(IO));
-        float *__restrict__ dBg = p.dB + (size_t)bg * 16 * (size_t)L;
-        float *__restrict__ dCg = p.dC + (size_t)bg * 16 * (size_t)L;
+        float *__restrict__ dBg = WS ? p.ws + ((size_t)blockIdx.x + bg) * 32 * (size_t)L : p.dB + (size_t)bg * 16 * (size_t)L;
+        float *__restrict__ dCg = WS ? dBg + 16 * (size_t)L : p.dC + (size_t)bg * 16 * (size_t)L;
         const size_t urow0 = DIRS ? ((size_t)(b * p.Gu + ug) * p.dpg + cin0) : r0;   // row of u / dout
         // bias / D are read-only for the whole launch: constant address space -> scalar loads (no VGPR, no vmcnt slot)
         typedef const float __attribute__((address_space(4))) *cfp;
@@ -87,9 +89,13 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
         //     state pairs of channel k; behind the last channel of a chunk the first channel of the NEXT chunk;
         //   * the B / C tile of the next chunk before the flush of this one.
         // Rows are addressed through buffer resources: a position outside the row reads 0 and drops the store.
-        const int tm = tid >> 8, tit = tid & 255, tnp = tit >> 5, tq4 = tit & 31;   // this thread's tile item
-        const int tj0 = (tq4 & 1) * 2, tsg = tq4 >> 1;
+        // tile item of this thread: waves 0-3 stage B, waves 4-7 stage C (wave-uniform, so the resource stays scalar);
+        // (pair, 4 positions) from the lane.  `opaque_tid()` keeps these cheap values from being hoisted out of the chunk
+        // loop and then spilled around the channel loop, which needs every register.
+        auto opaque_tid = [&]() { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; };
+        const int tm = wave >> 2;
         auto tile_load = [&](int chunk_, f4 &lo4, f4 &hi4) {
+            const int tit = opaque_tid() & 255, tnp = tit >> 5, tq4 = tit & 31;
             const int pos = chunk_ * CHUNK + tq4 * 4;
             const __amdgpu_buffer_rsrc_t rs = tm ? rsC : rsB;
             lo4 = buf_load4m<VEC, IO>(rs, (unsigned)(2 * tnp) * L, pos, L, rev);
@@ -120,8 +126,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
             const int base = chunk * CHUNK;
             const int chunk_next = chunk > 0 ? chunk - 1 : 0;
             __syncthreads();   // the previous flush has read the slots: slot 0 may become the tile again
-            tile[tm * 512 + (tnp * 4 + tj0) * 16 + tsg] = f4{tlo.x, thi.x, tlo.y, thi.y};
-            tile[tm * 512 + (tnp * 4 + tj0 + 1) * 16 + tsg] = f4{tlo.z, thi.z, tlo.w, thi.w};
+            {
+                const int tit = opaque_tid() & 255, tnp = tit >> 5, tq4 = tit & 31, tj0 = (tq4 & 1) * 2, tsg = tq4 >> 1;
+                f4 *td = tile + tm * 512 + (tnp * 4 + tj0) * 16 + tsg;
+                td[0] = f4{tlo.x, thi.x, tlo.y, thi.y};
+                td[16] = f4{tlo.z, thi.z, tlo.w, thi.w};
+            }
             __syncthreads();
 
             f2 accB[2][T], accC[2][T];
@@ -293,29 +303,47 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
             __syncthreads();   // every wave is done with the tile
             // ---- this wave's dB / dC sums -> its slot, [matrix][state][position], halves swizzled against bank conflicts
             {
-                const int sw = ((seg >> 2) & 1) << 2;
+                const int l2 = opaque_tid() & 63, row2 = l2 >> 4, seg2 = l2 & 15, sw = ((seg2 >> 2) & 1) << 2;
+                float *s0 = slot + (((4 * row2) * CHUNK + 8 * seg2) ^ sw), *s1 = slot + (((4 * row2) * CHUNK + 8 * seg2 + 4) ^ sw);
 #pragma unroll
                 for (int pi = 0; pi < 2; ++pi)
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
-                        const int o = (4 * row + 2 * pi + s) * CHUNK + 8 * seg;
-                        *reinterpret_cast<f4 *>(slot + (o ^ sw)) = f4{accB[pi][0][s], accB[pi][1][s], accB[pi][2][s], accB[pi][3][s]};
-                        *reinterpret_cast<f4 *>(slot + ((o + 4) ^ sw)) = f4{accB[pi][4][s], accB[pi][5][s], accB[pi][6][s], accB[pi][7][s]};
-                        *reinterpret_cast<f4 *>(slot + 2048 + (o ^ sw)) = f4{accC[pi][0][s], accC[pi][1][s], accC[pi][2][s], accC[pi][3][s]};
-                        *reinterpret_cast<f4 *>(slot + 2048 + ((o + 4) ^ sw)) = f4{accC[pi][4][s], accC[pi][5][s], accC[pi][6][s], accC[pi][7][s]};
+                        const int o = (2 * pi + s) * CHUNK;
+                        *reinterpret_cast<f4 *>(s0 + o) = f4{accB[pi][0][s], accB[pi][1][s], accB[pi][2][s], accB[pi][3][s]};
+                        *reinterpret_cast<f4 *>(s1 + o) = f4{accB[pi][4][s], accB[pi][5][s], accB[pi][6][s], accB[pi][7][s]};
+                        *reinterpret_cast<f4 *>(s0 + 2048 + o) = f4{accC[pi][0][s], accC[pi][1][s], accC[pi][2][s], accC[pi][3][s]};
+                        *reinterpret_cast<f4 *>(s1 + 2048 + o) = f4{accC[pi][4][s], accC[pi][5][s], accC[pi][6][s], accC[pi][7][s]};
                     }
             }
             __syncthreads();
-            // ---- add the NW slots; one global atomic per element, 64 consecutive positions per wave instruction
+            // ---- add the NW slots: every thread owns 2 x 4 consecutive positions; all 16 reads are issued before the adds
+            {
+                const int t2 = opaque_tid();
+                f4 v[2][NW];
 #pragma unroll
-            for (int e = 0; e < SLOT / (NW * 64); ++e) {
-                const int idx = e * (NW * 64) + tid;
-                const int phys = idx ^ (((idx >> 5) & 1) << 2);
-                float v = 0.0f;
+                for (int e = 0; e < 2; ++e) {
+                    const int i4 = e * (NW * 64) + t2, phys = i4 ^ ((i4 >> 3) & 1);
 #pragma unroll
-                for (int w = 0; w < NW; ++w) v += slots[w * SLOT + phys];
-                const int mat = idx >> 11, nn = (idx >> 7) & 15, pos = base + (idx & 127);
-                if (pos < L) atomicAdd((mat ? dCg : dBg) + (size_t)nn * L + (rev ? L - 1 - pos : pos), v);
+                    for (int w = 0; w < NW; ++w) v[e][w] = *reinterpret_cast<const f4 *>(slots + w * SLOT + 4 * phys);
+                }
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const f4 r = ((v[e][0] + v[e][1]) + (v[e][2] + v[e][3])) + ((v[e][4] + v[e][5]) + (v[e][6] + v[e][7]));
+                    const int idx = 4 * (e * (NW * 64) + t2);
+                    const int mat = idx >> 11, nn = (idx >> 7) & 15, pos = base + (idx & 127);
+                    float *dst = (mat ? dCg : dBg) + (size_t)nn * L;
+                    if (WS) {   // L % 4 == 0: the four positions are inside the row together
+                        if (pos < L) {
+                            if (!rev) *reinterpret_cast<f4 *>(dst + pos) = r;
+                            else *reinterpret_cast<f4 *>(dst + (L - 4 - pos)) = f4{r.w, r.z, r.y, r.x};
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (pos + q < L) atomicAdd(dst + (rev ? L - 1 - pos - q : pos + q), r[q]);
+                    }
+                }
             }
         }
         // ---- dA / dD / ddelta_bias of this wave's channels: sums over the batch -> global atomics
@@ -334,9 +362,24 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
     }
 }
 
-template <bool VEC, typename IO, bool DIRS>
+// dB/dC[bg] = sum of the partial tiles of the workgroups whose rows touch (batch, group) bg
+__global__ __launch_bounds__(256) void scan_bwd_sr_reduce_kernel(const float *__restrict__ ws, float *__restrict__ dB, float *__restrict__ dC,
+                                                                 int L, int dpg, int rows_per_wg, int n4) {
+    const int nblk = (n4 + 255) / 256, bg = blockIdx.x / nblk;
+    const int i = (blockIdx.x - bg * nblk) * 256 + threadIdx.x;   // float4 index inside the (dB | dC) tile of 32 * L floats
+    if (i >= n4) return;
+    const long long r_lo = (long long)bg * dpg, r_hi = r_lo + dpg - 1;
+    const int w0 = (int)(r_lo / rows_per_wg), w1 = (int)(r_hi / rows_per_wg);
+    f4 acc = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int w = w0; w <= w1; ++w) acc += *reinterpret_cast<const f4 *>(ws + ((size_t)w + bg) * 32 * (size_t)L + 4 * (size_t)i);
+    const size_t o = 4 * (size_t)i, half = 16 * (size_t)L;
+    float *dst = o < half ? dB + (size_t)bg * half + o : dC + (size_t)bg * half + (o - half);
+    *reinterpret_cast<f4 *>(dst) = acc;
+}
+
+template <bool VEC, typename IO, bool DIRS, bool WS>
 int launch_sr(const ScanBwdParams &p, int nwg, hipStream_t s) {
-    auto kern = scan_bwd_sr_kernel<VEC, IO, DIRS>;
+    auto kern = scan_bwd_sr_kernel<VEC, IO, DIRS, WS>;
     static bool attr_set[SS2D_MAX_DEVICES] = {};   // per instantiation and device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SS2D_MAX_DEVICES) dev = 0;
@@ -362,21 +405,47 @@ int num_cus() {
 
 }  // namespace
 
-int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, hipStream_t s) {
-    // rows per workgroup: the same number for every CU, several resident rounds when there are more than
-    // NW * CW_MAX rows per CU
-    const long long total = (long long)p.batch * p.dim;
+namespace {
+// rows per workgroup: the same number for every CU, several resident rounds when there are more than
+// NW * CW_MAX rows per CU
+long long sr_rows_per_wg(long long total) {
     const int ncu = num_cus();
     long long per = (total + ncu - 1) / ncu;
     for (int m = 2; per > NW * CW_MAX; ++m) per = (total + (long long)ncu * m - 1) / ((long long)ncu * m);
-    if (per < NW) per = NW;
+    return per < NW ? NW : per;
+}
+template <bool VEC, typename IO, bool DIRS>
+int launch_sr_ws(const ScanBwdParams &p, int nwg, hipStream_t s) {
+    return p.ws ? launch_sr<VEC, IO, DIRS, true>(p, nwg, s) : launch_sr<VEC, IO, DIRS, false>(p, nwg, s);
+}
+}  // namespace
+
+size_t ss2d_scan_bwd_sr_ws_bytes(int batch, int dim, int L, int ngroups) {
+    const long long total = (long long)batch * dim, per = sr_rows_per_wg(total);
+    const long long nwg = (total + per - 1) / per;
+    return (size_t)(nwg + (long long)batch * ngroups) * 32 * (size_t)L * sizeof(float);
+}
+
+int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, float *ws, size_t ws_bytes, hipStream_t s) {
+    const long long total = (long long)p.batch * p.dim, per = sr_rows_per_wg(total);
     p.rows_per_wg = (int)per;
     const long long nwg = (total + per - 1) / per;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidConfiguration;
+    // the partial-tile path needs 16-byte rows (L % 4) for its reduction kernel and a big enough, aligned workspace
+    p.ws = (ws && (p.L % 4 == 0) && (((uintptr_t)ws | (uintptr_t)p.dB | (uintptr_t)p.dC) & 15) == 0 &&
+            ws_bytes >= ss2d_scan_bwd_sr_ws_bytes(p.batch, p.dim, p.L, p.G)) ? ws : nullptr;
+    int rc;
     if (dtype == SS2D_DTYPE_BF16) {
-        if (dirs) return vec4 ? launch_sr<true, bf16, true>(p, (int)nwg, s) : launch_sr<false, bf16, true>(p, (int)nwg, s);
-        return vec4 ? launch_sr<true, bf16, false>(p, (int)nwg, s) : launch_sr<false, bf16, false>(p, (int)nwg, s);
+        if (dirs) rc = vec4 ? launch_sr_ws<true, bf16, true>(p, (int)nwg, s) : launch_sr_ws<false, bf16, true>(p, (int)nwg, s);
+        else rc = vec4 ? launch_sr_ws<true, bf16, false>(p, (int)nwg, s) : launch_sr_ws<false, bf16, false>(p, (int)nwg, s);
+    } else {
+        if (dirs) rc = vec4 ? launch_sr_ws<true, float, true>(p, (int)nwg, s) : launch_sr_ws<false, float, true>(p, (int)nwg, s);
+        else rc = vec4 ? launch_sr_ws<true, float, false>(p, (int)nwg, s) : launch_sr_ws<false, float, false>(p, (int)nwg, s);
     }
-    if (dirs) return vec4 ? launch_sr<true, float, true>(p, (int)nwg, s) : launch_sr<false, float, true>(p, (int)nwg, s);
-    return vec4 ? launch_sr<true, float, false>(p, (int)nwg, s) : launch_sr<false, float, false>(p, (int)nwg, s);
+    if (rc || !p.ws) return rc;
+    const int n4 = 8 * p.L;   // float4s per (dB | dC) tile
+    const float *wsc = p.ws;
+    int L = p.L, dpg = p.dpg, rpw = p.rows_per_wg, n4v = n4;
+    void *args[] = {&wsc, &p.dB, &p.dC, &L, &dpg, &rpw, &n4v};
+    return (int)hipLaunchKernel(reinterpret_cast<const void *>(scan_bwd_sr_reduce_kernel), dim3((unsigned)((n4 + 255) / 256) * (unsigned)(p.batch * p.G)), dim3(256), args, 0, s);
 }

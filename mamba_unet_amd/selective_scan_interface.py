@@ -17,6 +17,21 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def _bwd_buffers(lib, dev, batch, dim, L, dstate, G, has_z, shA, shD, shbias, shB, shC):
+    """Gradient accumulators + workspace of one scan backward.  With a workspace (16 states, no z, L % 4 == 0) the
+    library WRITES dB / dC (partial tiles + one reduction pass): they need no zero-fill; dA / dD / dbias (and dB / dC
+    on the atomic path) come zero-filled out of one buffer.  Returns dA, dD, dbias, dB, dC, ws, ws_bytes."""
+    nbytes = 0 if has_z else int(lib.ss2d_scan_bwd_workspace_bytes(batch, dim, L, dstate, G))
+    if nbytes:
+        dA, dD, dbias = _lib.zeros_group(dev, shA, shD, shbias)
+        dB = torch.empty(shB, device=dev, dtype=torch.float32)
+        dC = torch.empty(shC, device=dev, dtype=torch.float32)
+        ws = torch.empty(nbytes // 4, device=dev, dtype=torch.float32)
+        return dA, dD, dbias, dB, dC, ws, nbytes
+    dA, dD, dbias, dB, dC = _lib.zeros_group(dev, shA, shD, shbias, shB, shC)
+    return dA, dD, dbias, dB, dC, None, 0
+
+
 def _prep(t, name, dtype=torch.float32):
     if t is None:
         return None
@@ -100,15 +115,16 @@ class SelectiveScanFn(torch.autograd.Function):
         lib = _lib.load()
         du, ddelta = torch.empty_like(u), torch.empty_like(u)
         sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
-        dA, dD, dbias, dB, dC = _lib.zeros_group(u.device, sh(A), sh(D), sh(bias), sh(B), sh(C))   # one fill launch
+        dA, dD, dbias, dB, dC, ws, wsb = _bwd_buffers(lib, u.device, batch, dim, L, dstate, G, z is not None,
+                                                       sh(A), sh(D), sh(bias), sh(B), sh(C))
         dz = torch.empty_like(z) if z is not None else None
         with torch.cuda.device(u.device):
-            rc = lib.ss2d_selective_scan_bwd(ctx.code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B), _lib.ptr(C),
-                                             _lib.ptr(D), _lib.ptr(z), _lib.ptr(bias), _lib.ptr(dout), _lib.ptr(ckpt),
-                                             _lib.ptr(du), _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC),
-                                             _lib.ptr(dD), _lib.ptr(dz), _lib.ptr(dbias), batch, dim, L, dstate, G,
-                                             int(ctx.delta_softplus), _stream())
-        _lib.check(rc, "ss2d_selective_scan_bwd")
+            rc = lib.ss2d_selective_scan_dir_bwd_ws(ctx.code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B), _lib.ptr(C),
+                                                    _lib.ptr(D), _lib.ptr(z), _lib.ptr(bias), _lib.ptr(dout), _lib.ptr(ckpt),
+                                                    _lib.ptr(du), _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC),
+                                                    _lib.ptr(dD), _lib.ptr(dz), _lib.ptr(dbias), batch, dim, L, dstate, G,
+                                                    int(ctx.delta_softplus), G, 0, 0, _lib.ptr(ws), wsb, _stream())
+        _lib.check(rc, "ss2d_selective_scan_dir_bwd_ws")
         if ctx.squeeze_B:
             dB = dB.squeeze(1)
         if ctx.squeeze_C:
@@ -189,16 +205,16 @@ class ScanMergeFn(torch.autograd.Function):
         dys2 = torch.empty((batch, 2, Dch, L), device=g.device, dtype=u.dtype)
         du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
         sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
-        dA, dD, dbias, dB, dC = _lib.zeros_group(g.device, sh(A), sh(D), sh(bias), sh(Bm), sh(Cm))   # one fill launch
+        dA, dD, dbias, dB, dC, ws, wsb = _bwd_buffers(lib, g.device, batch, dim, L, N, 4, False, sh(A), sh(D), sh(bias), sh(Bm), sh(Cm))
         with torch.cuda.device(g.device):
             rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_scatter")
-            rc = lib.ss2d_selective_scan_dir_bwd(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(Bm), _lib.ptr(Cm),
-                                                 _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
-                                                 _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
-                                                 _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
-                                                 ScanMergeFn.REV_MASK, ctx.bcs, _stream())
-            _lib.check(rc, "ss2d_selective_scan_dir_bwd")
+            rc = lib.ss2d_selective_scan_dir_bwd_ws(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(Bm), _lib.ptr(Cm),
+                                                    _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
+                                                    _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
+                                                    _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
+                                                    ScanMergeFn.REV_MASK, ctx.bcs, _lib.ptr(ws), wsb, _stream())
+            _lib.check(rc, "ss2d_selective_scan_dir_bwd_ws")
             dx = None
             if ctx.x_dtype is not None:   # all four directions' du -> dx in one pass (the adjoint of the scatter)
                 dx = torch.empty((batch, Dch, H, W), device=g.device, dtype=u.dtype)
@@ -284,7 +300,8 @@ class ScanCoreFn(torch.autograd.Function):
         dys2 = torch.empty((batch, 2, Dch, L), device=dev, dtype=io)
         du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
         sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
-        dA, dD, dbias, dB, dC = _lib.zeros_group(dev, sh(A), sh(D), sh(bias), (batch, 4, N, L), (batch, 4, N, L))
+        dA, dD, dbias, dB, dC, ws, wsb = _bwd_buffers(lib, dev, batch, dim, L, N, 4, False, sh(A), sh(D), sh(bias),
+                                                       (batch, 4, N, L), (batch, 4, N, L))
         if (Cx * L) % 4 == 0:
             B_, C_, bcs = xd[:, :, R:R + N], xd[:, :, R + N:], Cx * L
         else:
@@ -293,12 +310,12 @@ class ScanCoreFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_scatter")
-            rc = lib.ss2d_selective_scan_dir_bwd(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B_), _lib.ptr(C_),
-                                                 _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
-                                                 _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
-                                                 _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
-                                                 ScanMergeFn.REV_MASK, bcs, _stream())
-            _lib.check(rc, "ss2d_selective_scan_dir_bwd")
+            rc = lib.ss2d_selective_scan_dir_bwd_ws(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B_), _lib.ptr(C_),
+                                                    _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
+                                                    _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
+                                                    _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
+                                                    ScanMergeFn.REV_MASK, bcs, _lib.ptr(ws), wsb, _stream())
+            _lib.check(rc, "ss2d_selective_scan_dir_bwd_ws")
             dx = du2 = None
             if x_dt is not None:      # all four directions' du -> dx in one pass (the adjoint of the scatter)
                 dx = torch.empty((batch, Dch, H, W), device=dev, dtype=io)
