@@ -142,7 +142,9 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
 
             const int ps = base + 8 * seg + 2 * row;             // the two positions this lane stages and finishes
             const bool ok0 = ps < L, ok1 = ps + 1 < L;
-            const int sto = 8 * seg + 2 * row, sta = 8 * seg, stb = 8 * seg + 4;
+            // staging strip: [array][item pair p][segment] float2 -- the writer (row = p) and the readers (4 pairs of one
+            // segment, one ds_read_b64 each) both touch 32 distinct banks per instruction
+            const int sto = 32 * row + 2 * seg, sta = 2 * seg;
             for (int k = 0; k < nmine; ++k) {
                 const bool lastk = k == klast;
                 const int kn = lastk ? 0 : k + 1, chn = lastk ? chunk_next : chunk;
@@ -163,12 +165,12 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 f2 dtp[4], dup[4], dyp[4];                            // pairs of neighbouring positions (see pk_*_sel)
                 {
-                    const f4 a0 = *reinterpret_cast<const f4 *>(st + sta), a1 = *reinterpret_cast<const f4 *>(st + stb);
-                    const f4 b0 = *reinterpret_cast<const f4 *>(st + CHUNK + sta), b1 = *reinterpret_cast<const f4 *>(st + CHUNK + stb);
-                    const f4 c0 = *reinterpret_cast<const f4 *>(st + 2 * CHUNK + sta), c1 = *reinterpret_cast<const f4 *>(st + 2 * CHUNK + stb);
-                    dtp[0] = f2{a0.x, a0.y}; dtp[1] = f2{a0.z, a0.w}; dtp[2] = f2{a1.x, a1.y}; dtp[3] = f2{a1.z, a1.w};
-                    dup[0] = f2{b0.x, b0.y}; dup[1] = f2{b0.z, b0.w}; dup[2] = f2{b1.x, b1.y}; dup[3] = f2{b1.z, b1.w};
-                    dyp[0] = f2{c0.x, c0.y}; dyp[1] = f2{c0.z, c0.w}; dyp[2] = f2{c1.x, c1.y}; dyp[3] = f2{c1.z, c1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        dtp[j] = *reinterpret_cast<const f2 *>(st + sta + 32 * j);
+                        dup[j] = *reinterpret_cast<const f2 *>(st + CHUNK + sta + 32 * j);
+                        dyp[j] = *reinterpret_cast<const f2 *>(st + 2 * CHUNK + sta + 32 * j);
+                    }
                 }
                 float *rec = recw + k * REC + 4 * row;                    // + 0: carries, + 16: dA, + 32: dD / dbias of this row
                 const f4 rcv = *reinterpret_cast<const f4 *>(rec);       // adjoint entering from the right
