@@ -103,6 +103,22 @@ int ss2d_selective_scan_dir_bwd_ws(int dtype, const void *u, const void *delta, 
                                    int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask,
                                    long long bc_bg_stride, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ss2d_selective_scan_dir_bwd_ws for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference: it exists only for those callers.
+ * The workspace is a fixed SS2D_STATIC_WS_BYTES array inside the library's code object (one copy per GPU, held until the
+ * process ends); the call allocates nothing and frees nothing.  Same arguments, outputs and zero-fill contract as
+ * ss2d_selective_scan_dir_bwd_ws with a workspace (dB / dC written; dA, dD, ddelta_bias accumulated: caller zero-fills).
+ * Rejected with a negative code: shapes for which ss2d_scan_bwd_workspace_bytes() is 0 (dstate != 16, L % 4 != 0), a z
+ * gate, and shapes that need more than SS2D_STATIC_WS_BYTES.  All calls on one GPU share the array: calls that overlap
+ * in time on one GPU (different streams) race; calls on one stream are ordered and safe. */
+#define SS2D_STATIC_WS_BYTES (64u << 20)
+int ss2d_selective_scan_dir_bwd_static(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                       const void *C, const float *D, const void *z, const float *delta_bias,
+                                       const void *dout, const float *ckpt, void *du, void *ddelta, float *dA, float *dB,
+                                       float *dC, float *dD, void *dz, float *ddelta_bias, int batch, int dim, int L,
+                                       int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask,
+                                       long long bc_bg_stride, void *stream);
+
 /* CrossScan (mamba_sys.py:403-404): x (B, D, H, W) -> xs (B, 4, D, H*W); _bwd is its adjoint
  * (sums the four directions back into dx). */
 int ss2d_cross_scan_fwd(int dtype, const void *x, void *xs, int B, int D, int H, int W, void *stream);

@@ -21,6 +21,8 @@ struct ScanBwdParams {
 // kernel (deterministic, no zero-fill needed), without it they are accumulated with float atomics.
 int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, float *ws, size_t ws_bytes, hipStream_t s);
 size_t ss2d_scan_bwd_sr_ws_bytes(int batch, int dim, int L, int ngroups);
+// Device address (on the current device) of the SS2D_STATIC_WS_BYTES workspace that lives in the code object.
+int ss2d_scan_bwd_sr_static_ws(float **ptr);
 
 // Packed fp32 math with one operand broadcast from HALF of a register pair (op_sel), so that `splat(x) * v` needs no
 // v_mov to build the splat: `s` is a pair of neighbouring values (two consecutive positions as they come out of an

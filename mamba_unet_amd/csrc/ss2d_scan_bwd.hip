@@ -370,9 +370,39 @@ extern "C" int ss2d_selective_scan_dir_bwd(int dtype, const void *u, const void 
                                           bc_bg_stride, nullptr, 0, stream);
 }
 
+// SS2D_BWD_KERNEL=general keeps every shape on the general kernel (A/B runs); read once
+static bool force_general_kernel() {
+    static const bool v = [] { const char *e = getenv("SS2D_BWD_KERNEL"); return e && e[0] == 'g'; }();
+    return v;
+}
+
 extern "C" size_t ss2d_scan_bwd_workspace_bytes(int batch, int dim, int L, int dstate, int ngroups) {
+    if (force_general_kernel()) return 0;
     if (batch <= 0 || dim <= 0 || L <= 0 || ngroups <= 0 || dstate != 16 || L % 4) return 0;   // only the 16-state kernel uses one
     return ss2d_scan_bwd_sr_ws_bytes(batch, dim, L, ngroups);
+}
+
+extern "C" int ss2d_selective_scan_dir_bwd_static(int dtype, const void *u, const void *delta, const float *A, const void *B,
+                                                  const void *C, const float *D, const void *z, const float *delta_bias,
+                                                  const void *dout, const float *ckpt, void *du, void *ddelta, float *dA,
+                                                  float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch,
+                                                  int dim, int L, int dstate, int ngroups, int delta_softplus, int u_groups,
+                                                  unsigned rev_mask, long long bc_bg_stride, void *stream) {
+    if (z != nullptr || dz != nullptr) { ss2d_set_error("selective_scan_bwd_static: the z gate is not supported by this entry point"); return -7; }
+    const size_t need = ss2d_scan_bwd_workspace_bytes(batch, dim, L, dstate, ngroups);
+    if (need == 0) { ss2d_set_error("selective_scan_bwd_static: needs dstate == 16 and L %% 4 == 0 (got dstate %d, L %d)", dstate, L); return -7; }
+    if (need > SS2D_STATIC_WS_BYTES) {
+        ss2d_set_error("selective_scan_bwd_static: this shape needs a %zu-byte workspace, the built-in one holds %u", need, SS2D_STATIC_WS_BYTES);
+        return -8;
+    }
+    if ((((uintptr_t)dB | (uintptr_t)dC | (uintptr_t)A | (uintptr_t)ckpt) & 15) != 0) {
+        ss2d_set_error("selective_scan_bwd_static: A, ckpt, dB, dC must be 16-byte aligned"); return -7; }
+    float *ws = nullptr;
+    const int rc = ss2d_scan_bwd_sr_static_ws(&ws);
+    if (rc) { ss2d_set_error("selective_scan_bwd_static: hipGetSymbolAddress failed: %s", hipGetErrorString((hipError_t)rc)); return rc; }
+    return ss2d_selective_scan_dir_bwd_ws(dtype, u, delta, A, B, C, D, nullptr, delta_bias, dout, ckpt, du, ddelta, dA, dB, dC, dD,
+                                          nullptr, ddelta_bias, batch, dim, L, dstate, ngroups, delta_softplus, u_groups, rev_mask,
+                                          bc_bg_stride, ws, SS2D_STATIC_WS_BYTES, stream);
 }
 
 extern "C" int ss2d_selective_scan_dir_bwd_ws(int dtype, const void *u, const void *delta, const float *A, const void *B,
@@ -428,8 +458,7 @@ extern "C" int ss2d_selective_scan_dir_bwd_ws(int dtype, const void *u, const vo
     hipStream_t s = (hipStream_t)stream;
     const bool dirs = rev_mask != 0 || u_groups != ngroups || bc_bg_stride != bc_dense;
     // the SS2D call pattern: 16 states, no gate -> state-row kernel (SS2D_BWD_KERNEL=general keeps the general one: A/B runs)
-    static const bool force_general = [] { const char *e = getenv("SS2D_BWD_KERNEL"); return e && e[0] == 'g'; }();
-    if (dstate == 16 && z == nullptr && !force_general && ((((uintptr_t)A | (uintptr_t)ckpt) & 15) == 0)) {
+    if (dstate == 16 && z == nullptr && !force_general_kernel() && ((((uintptr_t)A | (uintptr_t)ckpt) & 15) == 0)) {
         const int rc = ss2d_scan_bwd_sr_launch(dtype, p, vec4, dirs, static_cast<float *>(workspace), workspace_bytes, s);
         if (rc) ss2d_set_error("selective_scan_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
         return rc;

@@ -422,6 +422,27 @@ int launch_sr_ws(const ScanBwdParams &p, int nwg, hipStream_t s) {
 }
 }  // namespace
 
+// ---- the workspace of ss2d_selective_scan_dir_bwd_static: a fixed array in the code object, for callers that cannot
+// allocate.  Every GPU the library runs on holds its own copy at its own address; the name below is only a host-side
+// handle for hipGetSymbolAddress, never a device pointer.
+static __device__ __align__(256) float scratch[SS2D_STATIC_WS_BYTES / sizeof(float)];
+
+int ss2d_scan_bwd_sr_static_ws(float **ptr) {
+    static float *dev_ptr[SS2D_MAX_DEVICES] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= SS2D_MAX_DEVICES) return (int)hipErrorInvalidDevice;
+    if (!dev_ptr[dev]) {   // once per device, with that device current
+        void *q = nullptr;
+        e = hipGetSymbolAddress(&q, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        dev_ptr[dev] = static_cast<float *>(q);
+    }
+    *ptr = dev_ptr[dev];
+    return 0;
+}
+
 size_t ss2d_scan_bwd_sr_ws_bytes(int batch, int dim, int L, int ngroups) {
     const long long total = (long long)batch * dim, per = sr_rows_per_wg(total);
     const long long nwg = (total + per - 1) / per;
