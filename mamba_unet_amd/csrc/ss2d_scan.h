@@ -80,6 +80,20 @@ __device__ __forceinline__ void row_sum2_to_lane15(float &x, float &y) {
 #undef SS2D_ASTEP
 }
 
+// six row sums at once: the chains cover each other's DPP hazard, no s_nop between the steps
+__device__ __forceinline__ void row_sum6_to_lane15(float &a, float &b, float &c, float &d, float &e, float &f) {
+#define SS2D_ASTEP6(n)                                                                             \
+    "v_add_f32_dpp %0, %0, %0 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %1, %1, %1 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %2, %2, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %3, %3, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %4, %4, %4 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %5, %5, %5 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" SS2D_ASTEP6(1) SS2D_ASTEP6(2) SS2D_ASTEP6(4) SS2D_ASTEP6(8)
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#undef SS2D_ASTEP6
+}
+
 // Sum four per-lane values over the 4 DPP rows of the wave: on return row r of the result holds the
 // total (over rows) of x_r.  v_permlane16_swap exchanges the odd rows of its first operand with the
 // even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the

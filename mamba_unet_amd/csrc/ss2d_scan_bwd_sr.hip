@@ -7,7 +7,9 @@
 // it walks its channels one after the other inside a chunk, the chunks from the end of the sequence to the start.
 //   * dB / dC are sums over the channels of a group: with the states on the rows and the channels in time, every
 //     lane simply keeps adding into 64 registers (an FMA instead of a multiply: free); once per chunk the 8 waves
-//     of the workgroup put their registers into LDS, add them up and send ONE global float atomic per element.
+//     of the workgroup put their registers into LDS, add them up and write the workgroup's partial tile to the
+//     workspace with plain stores (a second kernel adds the partial tiles of a (batch, group)); without a workspace
+//     ONE global float atomic per element.
 //     (The channel-row layout of ss2d_scan_bwd.hip needs a cross-row butterfly and an LDS read-modify-write per
 //     value instead: a quarter of its instructions.)
 //   * du / ddelta are sums over the 16 states = over the 4 rows: one v_permlane swap butterfly per channel-chunk
@@ -16,7 +18,9 @@
 //   * B / C of the chunk are staged once per workgroup in LDS (the tile aliases the flush area, which is idle then).
 //   * Work is dealt in (batch, channel) rows, not in (batch, group) units: every one of the 256 CUs gets the same
 //     number of rows (72 at config 2); a workgroup whose rows straddle a group boundary runs the parts one after
-//     the other.  One 512-thread workgroup per CU (LDS-bound on purpose), 2 waves per SIMD.
+//     the other.  One 512-thread workgroup per CU (LDS-bound on purpose), 2 waves per SIMD.  Inside a chunk the
+//     channels are dealt to the waves one at a time (LDS ticket counter), not split evenly up front.
+// Where the time goes is measured with the s_memtime probes of -DSS2D_SR_PROBE (make variant, tools/probe_bwd.py).
 #include <cstdlib>
 #include "ss2d_scan.h"
 #include "../../include/ss2d.h"
@@ -25,26 +29,49 @@ namespace {
 
 constexpr int T = 8;
 constexpr int CHUNK = 128;
-constexpr int NW = 8;                       // waves per workgroup
-constexpr int CW_MAX = 12;                  // channels per wave and part
+#ifndef SS2D_SR_NW
+#define SS2D_SR_NW 8
+#endif
+constexpr int NW = SS2D_SR_NW;              // waves per workgroup (8: one workgroup per CU; 4: two)
+constexpr int WG_PER_CU = 8 / NW;
+constexpr int NM = 512 / (NW * 64);         // B/C tile: matrices staged per thread
+constexpr int NE = 1024 / (NW * 64);        // flush: float4 groups per thread
+constexpr int CW_MAX = NW == 8 ? 12 : 10;                  // channels per wave and part
 constexpr int REC = 48;                     // per (wave, channel) record in LDS: 16 adjoint carries | 16 dA | 4 rows x {dD, dbias, -, -}
 constexpr int SLOT = 2 * 16 * CHUNK;        // floats per wave in the flush area: [dB|dC][state][position]
 constexpr int STG = 3 * CHUNK;              // per wave: softplus(delta), delta*u, dout of the current channel-chunk
-constexpr int LDS_FLOATS = NW * SLOT + NW * STG + NW * CW_MAX * REC;
-static_assert(LDS_FLOATS * 4 <= 160 * 1024, "one workgroup per CU");
+constexpr int LDS_FLOATS = NW * SLOT + NW * STG + NW * CW_MAX * REC + 4;   // + the channel ticket counter
+static_assert(NW == 8 || NW == 4, "tile staging and flush are laid out for 8 or 4 waves");
+static_assert(LDS_FLOATS * 4 * WG_PER_CU <= 160 * 1024, "WG_PER_CU workgroups per CU");
 static_assert(CHUNK == SS2D_SCAN_CHUNK, "checkpoint spacing is part of the ABI");
 
 // WS: dB/dC partial tiles go to the workspace with plain stores (slot = workgroup + (batch, group) index: unique,
 // and consecutive for the workgroups that share a (batch, group)); otherwise float atomics on dB/dC.
+#ifdef SS2D_SR_PROBE
+// timing probes (debug builds only: tools/probe_bwd.py): per wave, s_memtime deltas summed per phase
+__device__ unsigned long long *g_sr_probe;
+#define SR_NPROBE 16
+#define SR_PROBE(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                         pacc[i] += (unsigned)(t_ - tprev); tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SR_PROBE(i) do { } while (0)
+#endif
+
 template <bool VEC, typename IO, bool DIRS, bool WS>
-__global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParams p) {
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_bwd_sr_kernel(const ScanBwdParams p) {
     extern __shared__ __align__(16) float smem[];
+#ifdef SS2D_SR_PROBE
+    unsigned pacc[SR_NPROBE] = {};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
     float *slots = smem;                                        // [NW][SLOT]; slot 0 doubles as the B/C tile
     f4 *tile = reinterpret_cast<f4 *>(smem);                   // [B|C][pair][item pair][seg] f4, as in ss2d_scan_fwd.hip
     const int tid = threadIdx.x, lane = tid & 63, row = lane >> 4, seg = lane & 15;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *st = smem + NW * SLOT + wave * STG;
-    float *recw = smem + NW * SLOT + NW * STG + wave * (CW_MAX * REC);          // this wave's channel records
+    float *recs = smem + NW * SLOT + NW * STG;                                  // one record per channel of the part
+    int *ticket = reinterpret_cast<int *>(smem + NW * SLOT + NW * STG + NW * CW_MAX * REC);
     float *slot = slots + wave * SLOT;
 
     const int L = p.L, nchunks = p.nchunks;
@@ -59,12 +86,11 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
         long long part_hi = (long long)(bg + 1) * p.dpg;
         if (part_hi > hi) part_hi = hi;
         const int n = (int)(part_hi - part_lo);
-        const int cw = (n + NW - 1) / NW;                        // <= CW_MAX (host: rows_per_wg <= NW * CW_MAX)
-        const int k0 = wave * cw;
-        int nmine = n - k0;
-        nmine = nmine < 0 ? 0 : (nmine > cw ? cw : nmine);
-        const int klast = nmine > 0 ? nmine - 1 : 0;
-        const size_t r0 = (size_t)(part_lo + (nmine > 0 ? k0 : 0));   // (batch, channel) row of this wave's first channel
+        // The n <= NW * CW_MAX channels of the part are dealt to the waves one at a time inside every chunk (wave w starts
+        // with channel w, then takes tickets from an LDS counter): the two waves of a SIMD do not advance at the same
+        // rate, and with a fixed split the barrier in front of the flush waited 13 % of the kernel time for the slower one.
+        const int kfirst = wave < n ? wave : 0;                    // a wave without a channel still prefetches a valid row
+        const size_t r0 = (size_t)part_lo;                          // (batch, channel) row of the part's first channel
         const int cin0 = (int)(r0 - (size_t)bg * p.dpg);
         const int cdim0 = g * p.dpg + cin0;
         const bool rev = DIRS && ((p.rev_mask >> g) & 1u);
@@ -75,13 +101,13 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
         float *__restrict__ dBg = WS ? p.ws + ((size_t)blockIdx.x + bg) * 32 * (size_t)L : p.dB + (size_t)bg * 16 * (size_t)L;
         float *__restrict__ dCg = WS ? dBg + 16 * (size_t)L : p.dC + (size_t)bg * 16 * (size_t)L;
         const size_t urow0 = DIRS ? ((size_t)(b * p.Gu + ug) * p.dpg + cin0) : r0;   // row of u / dout
-        // bias / D are read-only for the whole launch: constant address space -> scalar loads (no VGPR, no vmcnt slot)
-        typedef const float __attribute__((address_space(4))) *cfp;
-        const cfp biasp = (cfp)(uintptr_t)(p.bias ? p.bias : p.A), Dp = (cfp)(uintptr_t)(p.D ? p.D : p.A);   // always a valid address
+        // bias / D come through the vector memory path like A (same address in every lane): a scalar load would share the
+        // lgkm counter with the LDS traffic and, returning out of order, force a full drain at the next LDS use
+        const float *biasp = p.bias ? p.bias : p.A, *Dp = p.D ? p.D : p.A;   // always a valid address
         const bool has_bias = p.bias != nullptr, has_D = p.D != nullptr;
         const unsigned rowbytes = (unsigned)L * sizeof(IO);
 
-        for (int i = lane; i < CW_MAX * REC; i += 64) recw[i] = 0.0f;
+        for (int i = tid; i < n * REC; i += NW * 64) recs[i] = 0.0f;   // visible to all waves behind the first barrier of the chunk loop
 
         // Everything that comes from memory is requested one step ahead and never under a branch (a load under a
         // branch makes the compiler wait for every outstanding load at the join):
@@ -93,13 +119,16 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
         // (pair, 4 positions) from the lane.  `opaque_tid()` keeps these cheap values from being hoisted out of the chunk
         // loop and then spilled around the channel loop, which needs every register.
         auto opaque_tid = [&]() { int t_ = tid; asm volatile("" : "+v"(t_)); return t_; };
-        const int tm = wave >> 2;
-        auto tile_load = [&](int chunk_, f4 &lo4, f4 &hi4) {
+        const int tm = NM == 1 ? wave >> 2 : 0;
+        auto tile_load = [&](int chunk_, f4 (&lo4)[NM], f4 (&hi4)[NM]) {
             const int tit = opaque_tid() & 255, tnp = tit >> 5, tq4 = tit & 31;
             const int pos = chunk_ * CHUNK + tq4 * 4;
-            const __amdgpu_buffer_rsrc_t rs = tm ? rsC : rsB;
-            lo4 = buf_load4m<VEC, IO>(rs, (unsigned)(2 * tnp) * L, pos, L, rev);
-            hi4 = buf_load4m<VEC, IO>(rs, (unsigned)(2 * tnp + 1) * L, pos, L, rev);
+#pragma unroll
+            for (int m = 0; m < NM; ++m) {
+                const __amdgpu_buffer_rsrc_t rs = (tm + m) ? rsC : rsB;
+                lo4[m] = buf_load4m<VEC, IO>(rs, (unsigned)(2 * tnp) * L, pos, L, rev);
+                hi4[m] = buf_load4m<VEC, IO>(rs, (unsigned)(2 * tnp + 1) * L, pos, L, rev);
+            }
         };
         f2 nu, nd, ny;
         f4 nAv, nck;
@@ -114,13 +143,13 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
             const int c_ = cdim0 + k_;
             nAv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.A + (size_t)c_ * 16, 64), 16 * row, 0, 0));
             nck = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.ckpt + ((r0 + k_) * nchunks + chunk_) * 16, 64), 16 * row, 0, 0));
-            nbias = biasp[c_];
-            nD = Dp[c_];
+            nbias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(biasp + c_, 4), 0, 0, 0));
+            nD = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(Dp + c_, 4), 0, 0, 0));
         };
-        f4 tlo, thi;
+        f4 tlo[NM], thi[NM];
         tile_load(nchunks - 1, tlo, thi);
-        input_load(0, nchunks - 1);
-        param_load(0, nchunks - 1);
+        input_load(kfirst, nchunks - 1);
+        param_load(kfirst, nchunks - 1);
 
         for (int chunk = nchunks - 1; chunk >= 0; --chunk) {
             const int base = chunk * CHUNK;
@@ -128,11 +157,16 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
             __syncthreads();   // the previous flush has read the slots: slot 0 may become the tile again
             {
                 const int tit = opaque_tid() & 255, tnp = tit >> 5, tq4 = tit & 31, tj0 = (tq4 & 1) * 2, tsg = tq4 >> 1;
-                f4 *td = tile + tm * 512 + (tnp * 4 + tj0) * 16 + tsg;
-                td[0] = f4{tlo.x, thi.x, tlo.y, thi.y};
-                td[16] = f4{tlo.z, thi.z, tlo.w, thi.w};
+#pragma unroll
+                for (int m = 0; m < NM; ++m) {
+                    f4 *td = tile + (tm + m) * 512 + (tnp * 4 + tj0) * 16 + tsg;
+                    td[0] = f4{tlo[m].x, thi[m].x, tlo[m].y, thi[m].y};
+                    td[16] = f4{tlo[m].z, thi[m].z, tlo[m].w, thi[m].w};
+                }
+                if (tit == 0 && tm == 0) *ticket = NW;      // channels 0 .. NW-1 are taken: wave w starts with channel w
             }
             __syncthreads();
+            SR_PROBE(9);
 
             f2 accB[2][T], accC[2][T];
 #pragma unroll
@@ -145,9 +179,15 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
             // staging strip: [array][item pair p][segment] float2 -- the writer (row = p) and the readers (4 pairs of one
             // segment, one ds_read_b64 each) both touch 32 distinct banks per instruction
             const int sto = 32 * row + 2 * seg, sta = 2 * seg;
-            for (int k = 0; k < nmine; ++k) {
-                const bool lastk = k == klast;
-                const int kn = lastk ? 0 : k + 1, chn = lastk ? chunk_next : chunk;
+            // tickets are drawn two channels ahead so that the LDS atomic's return is never waited for
+            int tk = 0;
+            if (lane == 0) tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            int kt = __builtin_amdgcn_readfirstlane(tk);               // this wave's next channel, if there is one
+            for (int k = wave; k < n;) {
+                SR_PROBE(0);
+                const bool lastk = kt >= n;
+                const int kn = lastk ? kfirst : kt, chn = lastk ? chunk_next : chunk;
+                if (lane == 0) tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const f2 cu = nu, cd = nd, cy = ny;
                 const f4 Av = nAv, ck = nck;
                 const float bias = has_bias ? nbias : 0.0f, Dc = has_D ? nD : 0.0f;
@@ -172,13 +212,14 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
                         dyp[j] = *reinterpret_cast<const f2 *>(st + 2 * CHUNK + sta + 32 * j);
                     }
                 }
-                float *rec = recw + k * REC + 4 * row;                    // + 0: carries, + 16: dA, + 32: dD / dbias of this row
+                float *rec = recs + k * REC + 4 * row;                    // + 0: carries, + 16: dA, + 32: dD / dbias of this row
                 const f4 rcv = *reinterpret_cast<const f4 *>(rec);       // adjoint entering from the right
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 float S = 0.0f;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) S += dtp[j].x + dtp[j].y;
+                SR_PROBE(1);
 
                 float ddt[T], ddu[T];                                   // sums over this row's 4 states
                 f2 dAp[2], rleft[2];
@@ -220,6 +261,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
                         for (int t = 0; t < T; ++t) { hh = fma2(a[t], hh, bb[t]); h[t] = hh; }
                     }
                     __builtin_amdgcn_sched_barrier(0);
+                    SR_PROBE(2 + 3 * pi);
                     // ---- adjoint r_l = a_l * (dy_l * C_l + r_{l+1}): lane-local suffix pass, row scan, true pass
                     f2 rr;
                     f4 Bn, Cn;
@@ -238,6 +280,7 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
                     }
                     if (pi == 0) param_load(kn, chn);   // in flight during pair 1
                     __builtin_amdgcn_sched_barrier(0);
+                    SR_PROBE(3 + 3 * pi);
                     f2 dAacc = f2{0.0f, 0.0f};
 #pragma unroll
                     for (int j = 3; j >= 0; --j) {
@@ -271,23 +314,19 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    SR_PROBE(4 + 3 * pi);
                     dAp[pi] = dAacc;
                     rleft[pi] = rr;                                           // lane 0: adjoint leaving the chunk on the left
                 }
-                if (seg == 0) *reinterpret_cast<f4 *>(rec) = f4{rleft[0].x, rleft[0].y, rleft[1].x, rleft[1].y};
-                {   // dA: row sums, accumulated over the chunks in LDS (4 lanes per instruction: the LDS float atomic is cheap here)
-                    float s0 = dAp[0].x, s1 = dAp[0].y, s2 = dAp[1].x, s3 = dAp[1].y;
-                    row_sum2_to_lane15(s0, s1);
-                    row_sum2_to_lane15(s2, s3);
-                    if (seg == 15) {
-                        atomicAdd(rec + 16, s0); atomicAdd(rec + 17, s1); atomicAdd(rec + 18, s2); atomicAdd(rec + 19, s3);
-                    }
-                }
+                const int kt2 = __builtin_amdgcn_readfirstlane(tk);   // drawn at the top: has long arrived, few LDS operations behind it
+                // No branch between the state pairs and the uses of ddu / ddt: LLVM sinks the 64 scalar FMAs that build them
+                // below the first branch it finds, which keeps dL/dh, B and w of BOTH pairs alive (96 registers).
                 // ---- sums over the 16 states = over the rows; row r ends up with positions 2r, 2r+1 of every segment
                 float e0 = ddu[0], e1 = ddu[2], e2 = ddu[4], e3 = ddu[6], o0 = ddu[1], o1 = ddu[3], o2 = ddu[5], o3 = ddu[7];
                 rows_reduce4x2(e0, e1, e2, e3, o0, o1, o2, o3);
                 float f0 = ddt[0], f1 = ddt[2], f2_ = ddt[4], f3 = ddt[6], g0 = ddt[1], g1 = ddt[3], g2 = ddt[5], g3 = ddt[7];
                 rows_reduce4x2(f0, f1, f2_, f3, g0, g1, g2, g3);
+                SR_PROBE(12);
                 const f2 dtq = *reinterpret_cast<const f2 *>(st + sto), dyq = *reinterpret_cast<const f2 *>(st + 2 * CHUNK + sto);   // re-read: 4 registers
                 float ddta = f0 * SS2D_LN2 + e0 * u0, ddtb = g0 * SS2D_LN2 + o0 * u1;
                 if (p.softplus) { ddta *= sg0; ddtb *= sg1; }
@@ -296,13 +335,27 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
                 buf_store2m<VEC, IO>(make_rsrc(static_cast<IO *>(p.du) + (r0 + k) * (size_t)L, rowbytes), ps, L, rev,
                                      f2{e0 * dtq.x + dyq.x * Dc, o0 * dtq.y + dyq.y * Dc});
                 buf_store2m<VEC, IO>(make_rsrc(static_cast<IO *>(p.ddelta) + (r0 + k) * (size_t)L, rowbytes), ps, L, rev, f2{ddta, ddtb});
-                float sD = dyq.x * u0 + dyq.y * u1, sb = ddta + ddtb;
-                row_sum2_to_lane15(sD, sb);
-                if (seg == 15) { atomicAdd(rec + 32, sD); atomicAdd(rec + 33, sb); }
+                SR_PROBE(13);
+                // ---- dA (4 states of this row), dD, ddelta_bias: row sums, accumulated over the chunks in the wave's LDS record
+                float s0 = dAp[0].x, s1 = dAp[0].y, s2 = dAp[1].x, s3 = dAp[1].y, sD = dyq.x * u0 + dyq.y * u1, sb = ddta + ddtb;
+                row_sum6_to_lane15(s0, s1, s2, s3, sD, sb);
+                if (seg == 15) {   // plain read-modify-write: the record is private to the wave
+                    f4 *qa = reinterpret_cast<f4 *>(rec + 16);
+                    f2 *qd = reinterpret_cast<f2 *>(rec + 32);
+                    const f4 va = *qa;
+                    const f2 vd = *qd;
+                    *qa = va + f4{s0, s1, s2, s3};
+                    *qd = vd + f2{sD, sb};
+                }
+                if (seg == 0) *reinterpret_cast<f4 *>(rec) = f4{rleft[0].x, rleft[0].y, rleft[1].x, rleft[1].y};
+                k = kt;
+                kt = kt2;
             }
             tile_load(chunk_next, tlo, thi);   // arrives during the flush
 
+            SR_PROBE(11);
             __syncthreads();   // every wave is done with the tile
+            SR_PROBE(14);
             // ---- this wave's dB / dC sums -> its slot, [matrix][state][position], halves swizzled against bank conflicts
             {
                 const int l2 = opaque_tid() & 63, row2 = l2 >> 4, seg2 = l2 & 15, sw = ((seg2 >> 2) & 1) << 2;
@@ -318,20 +371,23 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
                         *reinterpret_cast<f4 *>(s1 + 2048 + o) = f4{accC[pi][4][s], accC[pi][5][s], accC[pi][6][s], accC[pi][7][s]};
                     }
             }
+            SR_PROBE(15);
             __syncthreads();
+            SR_PROBE(8);
             // ---- add the NW slots: every thread owns 2 x 4 consecutive positions; all 16 reads are issued before the adds
             {
                 const int t2 = opaque_tid();
-                f4 v[2][NW];
+                f4 v[NE][NW];
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
+                for (int e = 0; e < NE; ++e) {
                     const int i4 = e * (NW * 64) + t2, phys = i4 ^ ((i4 >> 3) & 1);
 #pragma unroll
                     for (int w = 0; w < NW; ++w) v[e][w] = *reinterpret_cast<const f4 *>(slots + w * SLOT + 4 * phys);
                 }
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const f4 r = ((v[e][0] + v[e][1]) + (v[e][2] + v[e][3])) + ((v[e][4] + v[e][5]) + (v[e][6] + v[e][7]));
+                for (int e = 0; e < NE; ++e) {
+                    f4 r = (v[e][0] + v[e][1]) + (v[e][2] + v[e][3]);
+                    if (NW == 8) r = r + ((v[e][4 % NW] + v[e][5 % NW]) + (v[e][6 % NW] + v[e][7 % NW]));
                     const int idx = 4 * (e * (NW * 64) + t2);
                     const int mat = idx >> 11, nn = (idx >> 7) & 15, pos = base + (idx & 127);
                     float *dst = (mat ? dCg : dBg) + (size_t)nn * L;
@@ -347,21 +403,26 @@ __global__ __launch_bounds__(NW * 64) void scan_bwd_sr_kernel(const ScanBwdParam
                     }
                 }
             }
+            SR_PROBE(10);
         }
-        // ---- dA / dD / ddelta_bias of this wave's channels: sums over the batch -> global atomics
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (int i = lane; i < nmine * 16; i += 64) atomicAdd(p.dA + (size_t)cdim0 * 16 + i, recw[(i >> 4) * REC + 16 + (i & 15)]);
-        if (lane < nmine) {
-            const float *q = recw + lane * REC + 32;
-            if (p.dD) atomicAdd(p.dD + cdim0 + lane, (q[0] + q[4]) + (q[8] + q[12]));
-            if (p.dbias) atomicAdd(p.dbias + cdim0 + lane, (q[1] + q[5]) + (q[9] + q[13]));
+        // ---- dA / dD / ddelta_bias of the part's channels: sums over the batch -> global atomics
+        __syncthreads();   // the records of the last chunk are complete (the flush has barriers, but not behind the last record write)
+        for (int i = tid; i < n * 16; i += NW * 64) atomicAdd(p.dA + (size_t)cdim0 * 16 + i, recs[(i >> 4) * REC + 16 + (i & 15)]);
+        if (tid < n) {
+            const float *q = recs + tid * REC + 32;
+            if (p.dD) atomicAdd(p.dD + cdim0 + tid, (q[0] + q[4]) + (q[8] + q[12]));
+            if (p.dbias) atomicAdd(p.dbias + cdim0 + tid, (q[1] + q[5]) + (q[9] + q[13]));
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();   // before the next part zeroes the records
         part_lo = part_hi;
     }
+#ifdef SS2D_SR_PROBE
+    if (g_sr_probe && lane == 0) {
+        unsigned long long *q = g_sr_probe + ((size_t)blockIdx.x * NW + wave) * (SR_NPROBE + 1);
+        for (int i = 0; i < SR_NPROBE; ++i) q[i] = pacc[i];
+        q[SR_NPROBE] = __builtin_amdgcn_s_memtime() - tstart;
+    }
+#endif
 }
 
 // dB/dC[bg] = sum of the partial tiles of the workgroups whose rows touch (batch, group) bg
@@ -411,7 +472,7 @@ namespace {
 // rows per workgroup: the same number for every CU, several resident rounds when there are more than
 // NW * CW_MAX rows per CU
 long long sr_rows_per_wg(long long total) {
-    const int ncu = num_cus();
+    const int ncu = num_cus() * WG_PER_CU;
     long long per = (total + ncu - 1) / ncu;
     for (int m = 2; per > NW * CW_MAX; ++m) per = (total + (long long)ncu * m - 1) / ((long long)ncu * m);
     return per < NW ? NW : per;
@@ -426,6 +487,12 @@ int launch_sr_ws(const ScanBwdParams &p, int nwg, hipStream_t s) {
 // allocate.  Every GPU the library runs on holds its own copy at its own address; the name below is only a host-side
 // handle for hipGetSymbolAddress, never a device pointer.
 static __device__ __align__(256) float scratch[SS2D_STATIC_WS_BYTES / sizeof(float)];
+
+#ifdef SS2D_SR_PROBE
+extern "C" int ss2d_debug_set_probe(void *buf) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_sr_probe), &buf, sizeof(buf));
+}
+#endif
 
 int ss2d_scan_bwd_sr_static_ws(float **ptr) {
     static float *dev_ptr[SS2D_MAX_DEVICES] = {};
