@@ -29,11 +29,34 @@ BATCH, K, D, L, N = 24, 4, 192, 3136, 16
 KD = K * D
 CPU_SLICES = 24         # bounded CPU sample: the whole config-2 batch once, ~10 s of host time
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# HBM bytes per launch from the PMC counters (cannot be collected inside this process): separate rocprofv3 --pmc
-# passes of this very command, 2 x FETCH_SIZE x 1024 (gfx950 tallies a 128-byte read request as 64 bytes) +
-# WRITE_SIZE x 1024, averaged over the dispatches -- tools/profile_round.sh, profiles/r01/bench_pmc_summary_final.txt.
-# Valid for the config-2 shapes of this file only; re-measure when a kernel's memory behaviour changes.
-PMC_TRAFFIC_BYTES = {"scan_fwd_kernel<float>": 776664552, "scan_bwd_kernel<float>": 1337427072}
+# HBM bytes per launch and the VALU-busy share come from the PMC counters, which cannot be collected inside this
+# process: tools/profile_round.sh runs separate rocprofv3 --pmc passes of this very command and
+# tools/summarize_pmc.py writes profiles/rNN/bench_pmc.json (2 x FETCH_SIZE x 1024 -- gfx950 tallies a 128-byte read
+# request as 64 bytes -- + WRITE_SIZE x 1024, averaged over the dispatches) together with a hash of the scan kernel
+# sources it was taken with.  The newest such file is read here; `sources_match` says whether the kernels have
+# changed since (then the figures are stale and the round's profile has to be retaken).
+SCAN_SOURCES = ("ss2d_scan_fwd.hip", "ss2d_scan_bwd.hip", "ss2d_scan_bwd_sr.hip", "ss2d_scan.h", "ss2d_common.h")
+
+
+def scan_sources_hash():
+    import hashlib
+    h = hashlib.sha256()
+    for f in SCAN_SOURCES:
+        with open(os.path.join(ROOT, "mamba_unet_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc():
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_pmc.json")))
+    if not files:
+        return None
+    with open(files[-1]) as fh:
+        d = json.load(fh)
+    d["file"] = os.path.relpath(files[-1], ROOT)
+    d["sources_match"] = d.get("sources_hash") == scan_sources_hash()
+    return d
 
 
 def algorithmic_bytes(batch):
@@ -63,7 +86,9 @@ def cpu_baseline():
     fwd, bwd = algorithmic_bytes(nb)
     return {"value": round((fwd + bwd) / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
             "sample": f"{nb} of {BATCH} slices (B={nb}, K*D={KD}, L={L}, N={N}) fwd + autograd bwd of "
-                      f"oracle.selective_scan_ref, {dt:.2f} s", "seconds": round(dt, 3)}, (inp, y.detach(), leaves)
+                      f"oracle.selective_scan_ref (the time-step `unbind` form of the reference's loop, which spares "
+                      f"autograd the O(L^2) select_backward of the literal x[:, :, i] indexing), {dt:.2f} s",
+            "seconds": round(dt, 3)}, (inp, y.detach(), leaves)
 
 
 def main():
@@ -146,10 +171,14 @@ def main():
         step(evs[i])
     sync_all()
     elapsed = time.perf_counter() - t0
+    rccl_world_seen = 1
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ones = torch.ones(1, device=dev)          # proof on the record that `world` ranks took part (RCCL sum of ones)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        rccl_world_seen = int(ones.item())
 
     fwd_us = sum(e[0].elapsed_time(e[1]) for e in evs) / args.steps * 1e3
     bwd_us = sum(e[2].elapsed_time(e[3]) for e in evs) / args.steps * 1e3
@@ -170,8 +199,17 @@ def main():
             gy.backward(gdout.to(dev))
             rel = lambda a, b: float((a.double().cpu() - b.double()).norm() / b.double().norm())  # noqa: E731
             parity = {"out": rel(gy.detach(), cy), **{"d" + k: rel(gi[k].grad, leaves[k].grad) for k in gi}}
-        dominant_us, dominant_bytes, dominant = (bwd_us, bb, "scan_bwd_kernel<float>") if bwd_us >= fwd_us else (fwd_us, fb, "scan_fwd_kernel<float>")
+        # the backward is two launches: scan_bwd_sr_kernel + the small dB/dC partial-tile reduction that follows it
+        dominant_us, dominant_bytes, dominant = (bwd_us, bb, "scan_bwd_sr_kernel<float> (+ scan_bwd_sr_reduce_kernel)") \
+            if bwd_us >= fwd_us else (fwd_us, fb, "scan_fwd_kernel<float>")
         achieved = dominant_bytes / (dominant_us * 1e-6) / 1e9
+        pmc = load_pmc()
+        pk = "scan_bwd" if bwd_us >= fwd_us else "scan_fwd"
+        traffic = pmc["traffic_bytes"].get(pk) if pmc else None
+        valu = None
+        if pmc and pmc.get("valu"):
+            # the scan is bound by the vector ALU, not by HBM: busy share of the SIMDs at the clock the kernel ran at
+            valu = {"bound": "valu", "kernel": pk, **pmc["valu"].get(pk, {}), "source": pmc["file"], "sources_match": pmc["sources_match"]}
         line = {
             "metric": "SS2D selective-scan fwd+bwd achieved HBM GB/s (algorithmic bytes / time)",
             "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -181,9 +219,12 @@ def main():
                                    "d_state=16 fp32 fwd+bwd per GPU", "batch_per_gpu": BATCH, "KD": KD, "L": L,
                        "d_state": N, "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": PMC_TRAFFIC_BYTES.get(dominant),
-                         "traffic_source": "rocprofv3 --pmc passes recorded in profiles/r01/bench_pmc_summary_final.txt",
-                         "algorithmic_bytes_per_launch": dominant_bytes, "avg_launch_us": round(dominant_us, 2)},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "traffic_source": (pmc["file"] + (" (kernel sources unchanged since)" if pmc["sources_match"] else
+                                                            " (STALE: kernel sources changed since)")) if pmc else None,
+                         "algorithmic_bytes_per_launch": dominant_bytes, "avg_launch_us": round(dominant_us, 2),
+                         "limiter": "valu (see roofline_valu): HBM traffic is ~1.1x the algorithmic bytes, the vector ALU is what is busy"},
+            "roofline_valu": valu, "rccl_world_seen": rccl_world_seen,
             "frac_of_hbm_peak_fwd_bwd": round(value / world / HBM_PEAK_GBS, 4),
             "kernels_us": {"scan_fwd": round(fwd_us, 2), "scan_bwd": round(bwd_us, 2),
                            "fwd_GBs": round(fb / fwd_us / 1e3, 1), "bwd_GBs": round(bb / bwd_us / 1e3, 1)},

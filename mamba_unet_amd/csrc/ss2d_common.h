@@ -2,6 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
+#include <tuple>
+#include <utility>
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -189,6 +192,26 @@ __device__ __forceinline__ void store2m(IO *__restrict__ row, int pos, int L, bo
 
 // thread-local error string shared by the C-ABI entry points
 void ss2d_set_error(const char *fmt, ...);
+
+// Kernel launches report through hipLaunchKernel's own return value, kept in a thread-local until the entry point
+// collects it: hipGetLastError() would also return -- and clear -- an error that another library (torch) left on
+// this thread, misattributing it to this library and hiding it from its owner.
+inline int &ss2d_launch_rc_ref() { static thread_local int rc = 0; return rc; }
+inline int ss2d_take_launch_rc() { int &r = ss2d_launch_rc_ref(); const int v = r; r = 0; return v; }   // first failure since the last call
+template <typename... KArgs, size_t... I>
+inline hipError_t ss2d_launch_impl(void (*kern)(KArgs...), dim3 g, dim3 b, size_t shm, hipStream_t s, std::tuple<KArgs...> &t,
+                                   std::index_sequence<I...>) {
+    void *ptrs[] = {static_cast<void *>(&std::get<I>(t))...};
+    return hipLaunchKernel(reinterpret_cast<const void *>(kern), g, b, ptrs, shm, s);
+}
+template <typename... KArgs, typename... Args>
+inline void ss2d_launch(void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shm, hipStream_t s, Args &&...args) {
+    std::tuple<KArgs...> t{static_cast<KArgs>(args)...};
+    const hipError_t e = ss2d_launch_impl(kern, grid, block, shm, s, t, std::index_sequence_for<KArgs...>{});
+    if (e != hipSuccess && ss2d_launch_rc_ref() == 0) ss2d_launch_rc_ref() = (int)e;
+}
+// tuning knobs from the environment are read once per process
+inline long long ss2d_env_ll(const char *name, long long dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; }
 
 // Sum over the 64 lanes of the wave (LW = 64) or over this lane's 32-lane half (LW = 32), result in every lane:
 // four rotate-and-add DPP steps inside each 16-lane row (VALU), then the row totals through v_readlane.  A

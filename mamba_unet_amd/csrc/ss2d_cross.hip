@@ -326,8 +326,8 @@ void launch(bool merge, bool cl, bool vec, bool h, dim3 grid, hipStream_t s, con
     const dim3 block(256);
 #define SS2D_CROSS_LAUNCH(K)                                                                                         \
     do {                                                                                                             \
-        if (cl) { if (h) hipLaunchKernelGGL((K<true, bf16, T>), grid, block, 0, s, p); else hipLaunchKernelGGL((K<true, float, T>), grid, block, 0, s, p); } \
-        else    { if (h) hipLaunchKernelGGL((K<false, bf16, T>), grid, block, 0, s, p); else hipLaunchKernelGGL((K<false, float, T>), grid, block, 0, s, p); } \
+        if (cl) { if (h) ss2d_launch((K<true, bf16, T>), grid, block, 0, s, p); else ss2d_launch((K<true, float, T>), grid, block, 0, s, p); } \
+        else    { if (h) ss2d_launch((K<false, bf16, T>), grid, block, 0, s, p); else ss2d_launch((K<false, float, T>), grid, block, 0, s, p); } \
     } while (0)
     if (vec) { if (merge) SS2D_CROSS_LAUNCH(cross_merge_vec_kernel); else SS2D_CROSS_LAUNCH(cross_scan_vec_kernel); }
     else     { if (merge) SS2D_CROSS_LAUNCH(cross_merge_kernel); else SS2D_CROSS_LAUNCH(cross_scan_kernel); }
@@ -355,7 +355,7 @@ int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, i
     const uintptr_t amask = h ? 7 : 15;   // 4 elements
     const bool vec = (H % 4 == 0) && (W % 4 == 0) && (!cl || D % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & amask) == 0);
     if (small) launch<TileSmall>(merge, cl, vec, h, grid, s, p); else launch<TileBig>(merge, cl, vec, h, grid, s, p);
-    const int rc = (int)hipGetLastError();
+    const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
     return rc;
 }

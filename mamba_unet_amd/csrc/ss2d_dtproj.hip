@@ -64,9 +64,9 @@ extern "C" int ss2d_dt_proj_fwd(int dtype, const void *x, const float *w, void *
     const dim3 grid((unsigned)nwg), block(256);
     hipStream_t s = (hipStream_t)stream;
     const bool h = dtype == SS2D_DTYPE_BF16;
-    if (R == 6) { if (h) hipLaunchKernelGGL((dt_proj_fwd_kernel<6, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((dt_proj_fwd_kernel<6, float>), grid, block, 0, s, p); }
-    else        { if (h) hipLaunchKernelGGL((dt_proj_fwd_kernel<12, bf16>), grid, block, 0, s, p); else hipLaunchKernelGGL((dt_proj_fwd_kernel<12, float>), grid, block, 0, s, p); }
-    const int rc = (int)hipGetLastError();
+    if (R == 6) { if (h) ss2d_launch((dt_proj_fwd_kernel<6, bf16>), grid, block, 0, s, p); else ss2d_launch((dt_proj_fwd_kernel<6, float>), grid, block, 0, s, p); }
+    else        { if (h) ss2d_launch((dt_proj_fwd_kernel<12, bf16>), grid, block, 0, s, p); else ss2d_launch((dt_proj_fwd_kernel<12, float>), grid, block, 0, s, p); }
+    const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("dt_proj_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

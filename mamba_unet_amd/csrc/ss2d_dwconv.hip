@@ -348,8 +348,8 @@ template <bool FWD, int CD, int TW>
 void launch(const ConvParams &p, bool cl, bool h, unsigned n, hipStream_t s) {
 #define SS2D_CONV_LAUNCH(CLV, T)                                                                                   \
     do {                                                                                                           \
-        if (FWD) hipLaunchKernelGGL((dwconv_silu_fwd_kernel<CLV, CD, TW, T>), dim3(n), dim3(256), 0, s, p);        \
-        else hipLaunchKernelGGL((dwconv_silu_bwd_kernel<CLV, CD, TW, T>), dim3(n), dim3(256), 0, s, p);            \
+        if (FWD) ss2d_launch((dwconv_silu_fwd_kernel<CLV, CD, TW, T>), dim3(n), dim3(256), 0, s, p);        \
+        else ss2d_launch((dwconv_silu_bwd_kernel<CLV, CD, TW, T>), dim3(n), dim3(256), 0, s, p);            \
     } while (0)
     if (cl) { if (h) SS2D_CONV_LAUNCH(true, bf16); else SS2D_CONV_LAUNCH(true, float); }
     else    { if (h) SS2D_CONV_LAUNCH(false, bf16); else SS2D_CONV_LAUNCH(false, float); }
@@ -371,7 +371,7 @@ extern "C" int ss2d_dwconv3x3_silu_fwd(int dtype, const void *x, const float *w,
     const bool h = dtype == SS2D_DTYPE_BF16;
     if (narrow) launch<true, 32, 16>(p, channel_last_in != 0, h, n, s);
     else launch<true, 16, 32>(p, channel_last_in != 0, h, n, s);
-    rc = (int)hipGetLastError();
+    rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("dwconv3x3_silu_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -396,7 +396,8 @@ extern "C" int ss2d_dwconv3x3_silu_bwd(int dtype, const void *x, const float *w,
     long long groups = slots / cols;
     if (groups < 1) groups = 1;
     long long reps = (units + groups - 1) / groups;
-    if (const char *e = getenv("SS2D_DWCONV_REPS")) reps = atoll(e);  // tuning knob
+    static const long long env_reps = ss2d_env_ll("SS2D_DWCONV_REPS", 0);   // tuning knob, read once
+    if (env_reps > 0) reps = env_reps;
     if (reps > units) reps = units;
     if (reps < 1) reps = 1;
     p.groups_h = (int)((units + reps - 1) / reps);
@@ -406,7 +407,7 @@ extern "C" int ss2d_dwconv3x3_silu_bwd(int dtype, const void *x, const float *w,
     const bool h = dtype == SS2D_DTYPE_BF16;
     if (narrow) launch<false, 32, 16>(p, channel_last_in != 0, h, n, s);
     else launch<false, 16, 32>(p, channel_last_in != 0, h, n, s);
-    rc = (int)hipGetLastError();
+    rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("dwconv3x3_silu_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

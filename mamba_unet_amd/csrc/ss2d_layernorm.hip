@@ -151,14 +151,14 @@ void launch_ln(bool bwd, const LNParams &p, hipStream_t s) {
         long long nwg = (p.rows + 4 * rpw - 1) / (4 * rpw);
         if (nwg > 8192) nwg = 8192;
         const dim3 grid((unsigned)nwg), block(256);
-        if (half) { hipLaunchKernelGGL((ln_fwd_kernel<1, 32, TI, TO>), grid, block, 0, s, p); return; }
+        if (half) { ss2d_launch((ln_fwd_kernel<1, 32, TI, TO>), grid, block, 0, s, p); return; }
         switch (K) {
-            case 1: hipLaunchKernelGGL((ln_fwd_kernel<1, 64, TI, TO>), grid, block, 0, s, p); break;
-            case 2: hipLaunchKernelGGL((ln_fwd_kernel<2, 64, TI, TO>), grid, block, 0, s, p); break;
-            case 3: hipLaunchKernelGGL((ln_fwd_kernel<3, 64, TI, TO>), grid, block, 0, s, p); break;
-            case 4: hipLaunchKernelGGL((ln_fwd_kernel<4, 64, TI, TO>), grid, block, 0, s, p); break;
-            case 5: hipLaunchKernelGGL((ln_fwd_kernel<5, 64, TI, TO>), grid, block, 0, s, p); break;
-            default: hipLaunchKernelGGL((ln_fwd_kernel<6, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 1: ss2d_launch((ln_fwd_kernel<1, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 2: ss2d_launch((ln_fwd_kernel<2, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 3: ss2d_launch((ln_fwd_kernel<3, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 4: ss2d_launch((ln_fwd_kernel<4, 64, TI, TO>), grid, block, 0, s, p); break;
+            case 5: ss2d_launch((ln_fwd_kernel<5, 64, TI, TO>), grid, block, 0, s, p); break;
+            default: ss2d_launch((ln_fwd_kernel<6, 64, TI, TO>), grid, block, 0, s, p); break;
         }
         return;
     }
@@ -166,14 +166,14 @@ void launch_ln(bool bwd, const LNParams &p, hipStream_t s) {
     long long nwg = (p.rows + nwv * rpw - 1) / (nwv * rpw);
     if (nwg > 256) nwg = 256;
     const dim3 grid((unsigned)nwg), block(nwv * 64);
-    if (half) { hipLaunchKernelGGL((ln_bwd_kernel<1, 16, 32, TI, TO>), grid, block, 0, s, p); return; }
+    if (half) { ss2d_launch((ln_bwd_kernel<1, 16, 32, TI, TO>), grid, block, 0, s, p); return; }
     switch (K) {
-        case 1: hipLaunchKernelGGL((ln_bwd_kernel<1, 16, 64, TI, TO>), grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL((ln_bwd_kernel<2, 16, 64, TI, TO>), grid, block, 0, s, p); break;
-        case 3: hipLaunchKernelGGL((ln_bwd_kernel<3, 4, 64, TI, TO>), grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL((ln_bwd_kernel<4, 4, 64, TI, TO>), grid, block, 0, s, p); break;
-        case 5: hipLaunchKernelGGL((ln_bwd_kernel<5, 4, 64, TI, TO>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((ln_bwd_kernel<6, 4, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 1: ss2d_launch((ln_bwd_kernel<1, 16, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 2: ss2d_launch((ln_bwd_kernel<2, 16, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 3: ss2d_launch((ln_bwd_kernel<3, 4, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 4: ss2d_launch((ln_bwd_kernel<4, 4, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 5: ss2d_launch((ln_bwd_kernel<5, 4, 64, TI, TO>), grid, block, 0, s, p); break;
+        default: ss2d_launch((ln_bwd_kernel<6, 4, 64, TI, TO>), grid, block, 0, s, p); break;
     }
 }
 
@@ -187,7 +187,7 @@ int dispatch(bool bwd, int in_dtype, int out_dtype, const LNParams &p, void *str
     if (in_dtype == SS2D_DTYPE_F32 && out_dtype == SS2D_DTYPE_F32) launch_ln<float, float>(bwd, p, s);
     else if (in_dtype == SS2D_DTYPE_F32) launch_ln<float, bf16>(bwd, p, s);
     else launch_ln<bf16, bf16>(bwd, p, s);
-    const int rc = (int)hipGetLastError();
+    const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -392,20 +392,20 @@ int launch_head(bool bwd, const LNParams &p, const HeadParams &hp, hipStream_t s
         long long nwg = (p.rows + 255) / 256;      // 64 rows per wave and trip
         if (nwg > 8192) nwg = 8192;
         const dim3 grid((unsigned)nwg), block(256);
-        if (ncp == 4) hipLaunchKernelGGL((ln_head_fwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
-        else if (ncp == 10) hipLaunchKernelGGL((ln_head_fwd_kernel<10, TI, TO>), grid, block, 0, s, p, hp);
-        else hipLaunchKernelGGL((ln_head_fwd_kernel<16, TI, TO>), grid, block, 0, s, p, hp);
+        if (ncp == 4) ss2d_launch((ln_head_fwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
+        else if (ncp == 10) ss2d_launch((ln_head_fwd_kernel<10, TI, TO>), grid, block, 0, s, p, hp);
+        else ss2d_launch((ln_head_fwd_kernel<16, TI, TO>), grid, block, 0, s, p, hp);
     } else {
         const int nwv = ncp == 4 ? 16 : 8;
         long long nwg = (p.rows + nwv * 64 - 1) / (nwv * 64);    // 64 rows per wave and trip
         const long long cap = ncp == 4 ? 256 : 512;              // 4096 waves in all either way
         if (nwg > cap) nwg = cap;
         const dim3 grid((unsigned)nwg), block(nwv * 64);
-        if (ncp == 4) hipLaunchKernelGGL((ln_head_bwd_kernel<4, 16, TI, TO>), grid, block, 0, s, p, hp);
-        else if (ncp == 10) hipLaunchKernelGGL((ln_head_bwd_kernel<10, 8, TI, TO>), grid, block, 0, s, p, hp);
-        else hipLaunchKernelGGL((ln_head_bwd_kernel<16, 8, TI, TO>), grid, block, 0, s, p, hp);
+        if (ncp == 4) ss2d_launch((ln_head_bwd_kernel<4, 16, TI, TO>), grid, block, 0, s, p, hp);
+        else if (ncp == 10) ss2d_launch((ln_head_bwd_kernel<10, 8, TI, TO>), grid, block, 0, s, p, hp);
+        else ss2d_launch((ln_head_bwd_kernel<16, 8, TI, TO>), grid, block, 0, s, p, hp);
     }
-    return (int)hipGetLastError();
+    return ss2d_take_launch_rc();
 }
 
 int dispatch_head(bool bwd, int in_dtype, int out_dtype, const LNParams &p, const HeadParams &hp, void *stream, const char *name) {

@@ -165,12 +165,12 @@ void launch(bool bwd, const NormGateParams &p, hipStream_t s) {
         if (nwg > 8192) nwg = 8192;
         const dim3 grid((unsigned)nwg), block(256);
         switch (K) {
-            case 1: hipLaunchKernelGGL((normgate_fwd_kernel<1, IO>), grid, block, 0, s, p); break;
-            case 2: hipLaunchKernelGGL((normgate_fwd_kernel<2, IO>), grid, block, 0, s, p); break;
-            case 3: hipLaunchKernelGGL((normgate_fwd_kernel<3, IO>), grid, block, 0, s, p); break;
-            case 4: hipLaunchKernelGGL((normgate_fwd_kernel<4, IO>), grid, block, 0, s, p); break;
-            case 5: hipLaunchKernelGGL((normgate_fwd_kernel<5, IO>), grid, block, 0, s, p); break;
-            default: hipLaunchKernelGGL((normgate_fwd_kernel<6, IO>), grid, block, 0, s, p); break;
+            case 1: ss2d_launch((normgate_fwd_kernel<1, IO>), grid, block, 0, s, p); break;
+            case 2: ss2d_launch((normgate_fwd_kernel<2, IO>), grid, block, 0, s, p); break;
+            case 3: ss2d_launch((normgate_fwd_kernel<3, IO>), grid, block, 0, s, p); break;
+            case 4: ss2d_launch((normgate_fwd_kernel<4, IO>), grid, block, 0, s, p); break;
+            case 5: ss2d_launch((normgate_fwd_kernel<5, IO>), grid, block, 0, s, p); break;
+            default: ss2d_launch((normgate_fwd_kernel<6, IO>), grid, block, 0, s, p); break;
         }
         return;
     }
@@ -180,12 +180,12 @@ void launch(bool bwd, const NormGateParams &p, hipStream_t s) {
     if (nwg > 256) nwg = 256;
     const dim3 grid((unsigned)nwg), block(nwv * 64);
     switch (K) {
-        case 1: hipLaunchKernelGGL((normgate_bwd_kernel<1, 16, IO>), grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL((normgate_bwd_kernel<2, 16, IO>), grid, block, 0, s, p); break;
-        case 3: hipLaunchKernelGGL((normgate_bwd_kernel<3, 4, IO>), grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL((normgate_bwd_kernel<4, 4, IO>), grid, block, 0, s, p); break;
-        case 5: hipLaunchKernelGGL((normgate_bwd_kernel<5, 4, IO>), grid, block, 0, s, p); break;
-        default: hipLaunchKernelGGL((normgate_bwd_kernel<6, 4, IO>), grid, block, 0, s, p); break;
+        case 1: ss2d_launch((normgate_bwd_kernel<1, 16, IO>), grid, block, 0, s, p); break;
+        case 2: ss2d_launch((normgate_bwd_kernel<2, 16, IO>), grid, block, 0, s, p); break;
+        case 3: ss2d_launch((normgate_bwd_kernel<3, 4, IO>), grid, block, 0, s, p); break;
+        case 4: ss2d_launch((normgate_bwd_kernel<4, 4, IO>), grid, block, 0, s, p); break;
+        case 5: ss2d_launch((normgate_bwd_kernel<5, 4, IO>), grid, block, 0, s, p); break;
+        default: ss2d_launch((normgate_bwd_kernel<6, 4, IO>), grid, block, 0, s, p); break;
     }
 }
 
@@ -202,7 +202,7 @@ extern "C" int ss2d_outnorm_gate_fwd(int dtype, const void *y, const void *z, co
     int rc = check(p, dtype, "outnorm_gate_fwd");
     if (rc) return rc;
     if (dtype == SS2D_DTYPE_BF16) launch<bf16>(false, p, (hipStream_t)stream); else launch<float>(false, p, (hipStream_t)stream);
-    rc = (int)hipGetLastError();
+    rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("outnorm_gate_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -221,7 +221,7 @@ extern "C" int ss2d_outnorm_gate_bwd(int dtype, const void *dout, const void *y,
     if (rc) return rc;
     if (lddz < D || lddz % 4) { ss2d_set_error("outnorm_gate_bwd: lddz %d must be >= D and a multiple of 4", lddz); return -4; }
     if (dtype == SS2D_DTYPE_BF16) launch<bf16>(true, p, (hipStream_t)stream); else launch<float>(true, p, (hipStream_t)stream);
-    rc = (int)hipGetLastError();
+    rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("outnorm_gate_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

@@ -234,15 +234,15 @@ int launch_fwd(const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
     dim3 grid(p.nwg), block(NW * 64);
     const bool full = p.N == 16;
     if (has_z) {
-        if (vec4) hipLaunchKernelGGL((scan_fwd_kernel<NW, true, true, false, IO, DIRS>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scan_fwd_kernel<NW, true, false, false, IO, DIRS>), grid, block, 0, s, p);
+        if (vec4) ss2d_launch((scan_fwd_kernel<NW, true, true, false, IO, DIRS>), grid, block, 0, s, p);
+        else ss2d_launch((scan_fwd_kernel<NW, true, false, false, IO, DIRS>), grid, block, 0, s, p);
     } else if (vec4 && full) {
-        hipLaunchKernelGGL((scan_fwd_kernel<NW, false, true, true, IO, DIRS>), grid, block, 0, s, p);  // the SS2D call pattern
+        ss2d_launch((scan_fwd_kernel<NW, false, true, true, IO, DIRS>), grid, block, 0, s, p);  // the SS2D call pattern
     } else {
-        if (vec4) hipLaunchKernelGGL((scan_fwd_kernel<NW, false, true, false, IO, DIRS>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((scan_fwd_kernel<NW, false, false, false, IO, DIRS>), grid, block, 0, s, p);
+        if (vec4) ss2d_launch((scan_fwd_kernel<NW, false, true, false, IO, DIRS>), grid, block, 0, s, p);
+        else ss2d_launch((scan_fwd_kernel<NW, false, false, false, IO, DIRS>), grid, block, 0, s, p);
     }
-    return (int)hipGetLastError();
+    return ss2d_take_launch_rc();
 }
 template <typename IO, bool DIRS>
 int launch_fwd_nw(int nw, const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
@@ -288,7 +288,8 @@ extern "C" int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void 
     p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
     p.nchunks = ss2d_scan_num_chunks(L); p.softplus = delta_softplus;
     int nw = p.dpg >= 16 ? 4 : (p.dpg >= 8 ? 2 : 1);
-    if (const char *e = getenv("SS2D_FWD_NW")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nw = v; }  // tuning knob
+    static const int env_nw = (int)ss2d_env_ll("SS2D_FWD_NW", 0);   // tuning knob, read once
+    if (env_nw == 1 || env_nw == 2 || env_nw == 4) nw = env_nw;
     p.wgs_per_group = (p.dpg + nw * 4 - 1) / (nw * 4);
     const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
     if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_fwd: grid too large"); return -6; }

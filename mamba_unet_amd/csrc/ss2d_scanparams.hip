@@ -49,9 +49,9 @@ int run(bool bwd, ScanParamsArgs &p, void *stream, const char *name) {
     long long nwg = (total + 255) / 256;
     if (nwg > 2048) nwg = 2048;
     hipStream_t s = (hipStream_t)stream;
-    if (bwd) hipLaunchKernelGGL(scan_params_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(scan_params_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, s, p);
-    const int rc = (int)hipGetLastError();
+    if (bwd) ss2d_launch(scan_params_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else ss2d_launch(scan_params_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
     return rc;
 }
@@ -135,9 +135,9 @@ extern "C" int ss2d_xdbl_grad_pack(int dtype, const void *d_dts, const float *dB
     long long nwg = (total + 255) / 256;
     if (nwg > 16384) nwg = 16384;
     hipStream_t s = (hipStream_t)stream;
-    if (vec) { if (h) hipLaunchKernelGGL((xdbl_grad_pack_kernel<bf16, 4>), dim3((unsigned)nwg), dim3(256), 0, s, p); else hipLaunchKernelGGL((xdbl_grad_pack_kernel<float, 4>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
-    else     { if (h) hipLaunchKernelGGL((xdbl_grad_pack_kernel<bf16, 1>), dim3((unsigned)nwg), dim3(256), 0, s, p); else hipLaunchKernelGGL((xdbl_grad_pack_kernel<float, 1>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
-    const int rc = (int)hipGetLastError();
+    if (vec) { if (h) ss2d_launch((xdbl_grad_pack_kernel<bf16, 4>), dim3((unsigned)nwg), dim3(256), 0, s, p); else ss2d_launch((xdbl_grad_pack_kernel<float, 4>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
+    else     { if (h) ss2d_launch((xdbl_grad_pack_kernel<bf16, 1>), dim3((unsigned)nwg), dim3(256), 0, s, p); else ss2d_launch((xdbl_grad_pack_kernel<float, 1>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
+    const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("xdbl_grad_pack: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

@@ -299,7 +299,8 @@ extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float 
     // One wave per SIMD on every CU: the fp32 form cannot hold more (298 registers); the bf16 form could hold two
     // (242), but twice the workgroups flush twice the atomics and measured 5-10 % slower.
     long long target_waves = 1024;
-    if (const char *e = getenv("SS2D_WGRAD_WAVES")) { const long long v = atoll(e); if (v >= 4 && v <= 65536) target_waves = v; }  // tuning knob
+    static const long long env_waves = ss2d_env_ll("SS2D_WGRAD_WAVES", 0);   // tuning knob, read once
+    if (env_waves >= 4 && env_waves <= 65536) target_waves = env_waves;
     long long ks = (target_waves + tiles - 1) / tiles;
     const long long max_ks = (rows + 127) / 128;
     if (ks > max_ks) ks = max_ks;
@@ -310,10 +311,11 @@ extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float 
     const long long nwg = (ks / 4) * tiles;
     if (nwg > 0x7fffffffLL) { ss2d_set_error("linear_wgrad: grid too large"); return -6; }
     hipStream_t s = (hipStream_t)stream;
-    if (dtype == SS2D_DTYPE_BF16 && !getenv("SS2D_WGRAD_WIDEN")) hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);   // env: A/B against the fp32-MFMA form
-    else if (dtype == SS2D_DTYPE_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16>, dim3((unsigned)nwg), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL(wgrad_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, s, p);
-    const int rc = (int)hipGetLastError();
+    static const bool env_widen = getenv("SS2D_WGRAD_WIDEN") != nullptr;   // A/B against the fp32-MFMA form, read once
+    if (dtype == SS2D_DTYPE_BF16 && !env_widen) ss2d_launch(wgrad_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);   // env: A/B against the fp32-MFMA form
+    else if (dtype == SS2D_DTYPE_BF16) ss2d_launch(wgrad_kernel<bf16>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else ss2d_launch(wgrad_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("linear_wgrad: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
 }

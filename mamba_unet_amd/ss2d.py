@@ -3,10 +3,13 @@
 Host-side mirror of the reference's operator interface (code/networks/mamba_sys.py:267-716): same
 constructor arguments, same parameter names and shapes (checkpoint contract), same
 random-number consumption order at construction (so a given seed yields the reference's init), but
-`forward` runs:  in_proj (hipBLASLt) -> ss2d_dwconv3x3_silu (reads the channel-last x half of xz in
-place) -> ss2d_cross_scan -> x_proj / dt_proj contractions (rocBLAS batched GEMM) ->
-ss2d_selective_scan fwd/bwd -> ss2d_cross_merge (writes channel-last) -> LayerNorm, SiLU(z) gate,
-out_proj.
+`forward` runs (default, `SS2D.fused_directions = True`):  in_proj (hipBLASLt) -> ss2d_dwconv3x3_silu (reads the
+channel-last x half of xz in place) -> ss2d_dirs_scatter (row-major + column-major copy of x only) -> x_proj
+as one batched GEMM per orientation -> scan_core_fn: dt_proj, direction-aware selective scan
+(ss2d_selective_scan_dir_fwd / _bwd_ws: reversed directions read in place, B / C read in place from the x_proj
+output) and ss2d_dirs_gather (merge, channel-last) as one autograd node -> fused out_norm + SiLU(z) gate ->
+out_proj.  `fused_directions = False` keeps the literal pipeline of the reference
+(ss2d_cross_scan -> two batched GEMMs -> selective_scan_fn -> ss2d_cross_merge).
 """
 from __future__ import annotations
 
