@@ -8,8 +8,8 @@ bench.py reads (profiles/rNN/bench_pmc.json):
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes
 for wide coalesced reads (MI355X_MICROARCH.md, HBM section), so the corrected read traffic is 2 x FETCH_SIZE x 1024.
 SQ_ACTIVE_INST_VALU counts in units of 4 cycles summed over all SIMDs; GRBM_GUI_ACTIVE is the number of GPU clock
-cycles the dispatch was active, so   valu_busy = 4 x SQ_ACTIVE_INST_VALU / (n_simd x GRBM_GUI_ACTIVE)   and
-clock = GRBM_GUI_ACTIVE / duration (the chip runs the scan well below its 2.4 GHz peak clock)."""
+cycles the dispatch was active, summed over the 8 XCDs, so with cyc = GRBM_GUI_ACTIVE / 8:
+valu_busy = 4 x SQ_ACTIVE_INST_VALU / (n_simd x cyc)   and   clock = cyc / duration (the chip runs the scan well below its 2.4 GHz peak clock)."""
 import collections
 import csv
 import glob
@@ -20,6 +20,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_SIMD = 256 * 4
+N_XCD = 8          # GRBM_GUI_ACTIVE is summed over the 8 XCDs' GRBMs
 SCAN_SOURCES = ("ss2d_scan_fwd.hip", "ss2d_scan_bwd.hip", "ss2d_scan_bwd_sr.hip", "ss2d_scan.h", "ss2d_common.h")   # as bench.py
 
 
@@ -74,10 +75,11 @@ def main():
             v = {"SQ_ACTIVE_INST_VALU": act, "SQ_INSTS_VALU": ins}
             if gui:
                 v["GRBM_GUI_ACTIVE"] = gui
-                v["valu_busy"] = round(4 * act / (N_SIMD * gui), 4)
+                cyc = gui / N_XCD
+                v["valu_busy"] = round(4 * act / (N_SIMD * cyc), 4)
                 if k in dur_us:
-                    v["clock_ghz"] = round(gui / (dur_us[k] * 1e3), 3)
-                print(f"{k}: VALU busy = 4*SQ_ACTIVE_INST_VALU/({N_SIMD}*GRBM_GUI_ACTIVE) = {v['valu_busy']:.3f}"
+                    v["clock_ghz"] = round(cyc / (dur_us[k] * 1e3), 3)
+                print(f"{k}: VALU busy = 4*SQ_ACTIVE_INST_VALU/({N_SIMD}*GRBM_GUI_ACTIVE/{N_XCD}) = {v['valu_busy']:.3f}"
                       + (f", clock = {v['clock_ghz']:.2f} GHz" if "clock_ghz" in v else ""))
             valu[k] = v
     if len(sys.argv) > 2:
@@ -95,7 +97,7 @@ def main():
         out = {"sources_hash": h.hexdigest()[:16], "traffic_bytes": tb, "valu": vb, "durations_us": dur_us,
                "traffic_bytes_per_kernel": traffic,
                "how": "tools/profile_round.sh: separate rocprofv3 --pmc passes of `bench.py --steps 3`, averaged per dispatch; "
-                      "traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; valu_busy = 4*SQ_ACTIVE_INST_VALU/(1024*GRBM_GUI_ACTIVE)"}
+                      "traffic = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; valu_busy = 4*SQ_ACTIVE_INST_VALU/(1024*GRBM_GUI_ACTIVE/8)"}
         os.makedirs(os.path.dirname(os.path.abspath(sys.argv[2])), exist_ok=True)
         with open(sys.argv[2], "w") as fh:
             json.dump(out, fh, indent=1)
