@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=["train", "infer", "semi"], default="train")
+    ap.add_argument("--model1", choices=["unet", "vim"], default="unet", help="semi mode: the first network (reference default: unet)")
     ap.add_argument("--size", type=int, default=224)
     ap.add_argument("--classes", type=int, default=4)
     ap.add_argument("--batch", type=int, default=24, help="slices per GPU")
@@ -67,8 +68,12 @@ def main():
     SS2D.bf16_scan_io = args.dtype == "bf16"
     SS2D.fused_directions = not args.literal_directions
     torch.manual_seed(1337)                       # train_fully_supervised_2D_VIM.py:243-246
-    nets = [MambaUnet(img_size=args.size, num_classes=args.classes).to(dev) for _ in range(2 if args.mode == "semi" else 1)]
-    n_params = sum(p.numel() for p in nets[0].parameters())
+    if args.mode == "semi" and args.model1 == "unet":     # train_Semi_Mamba_UNet.py:302-303 (default model1) + :325 (model2)
+        from mamba_unet_amd.unet import UNet
+        nets = [UNet(in_chns=1, class_num=args.classes).to(dev), MambaUnet(img_size=args.size, num_classes=args.classes).to(dev)]
+    else:
+        nets = [MambaUnet(img_size=args.size, num_classes=args.classes).to(dev) for _ in range(2 if args.mode == "semi" else 1)]
+    n_params = sum(p.numel() for p in nets[-1].parameters())
     torch.manual_seed(1337 + rank)                # per-rank data and DropPath streams
     images = torch.rand(args.batch, 1, args.size, args.size, device=dev)
     labels = torch.randint(0, args.classes, (args.batch, args.size, args.size), device=dev, dtype=torch.uint8)
@@ -105,7 +110,7 @@ def main():
         o1, o2 = make_sgd(n1.parameters()), make_sgd(n2.parameters())
 
         def step(it):
-            return semi_step(n1, n2, o1, o2, images, labels, args.batch // 2, args.classes, it, max_it, 0.1)
+            return semi_step(n1, n2, o1, o2, images, labels, args.batch // 2, args.classes, it, max_it, 0.1, autocast_bf16=bf16)
 
     def sync_all():
         if dist is not None:

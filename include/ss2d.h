@@ -240,6 +240,22 @@ int ss2d_ln_head_bwd(int in_dtype, int out_dtype, const void *dlogits, const voi
                      float *dgamma, float *dbeta, float *dw_head, long long batch, int H, int W, int ps, int D,
                      int classes, void *stream);
 
+/* Statistics of the segmentation losses in one pass over the logits: softmax over the class axis, the per-class sums of
+ * DiceLoss over the WHOLE batch (code/utils/losses.py:179-215: intersect, y_sum, z_sum of _dice_loss, one-hot of :186-192)
+ * and the summed cross entropy of nn.CrossEntropyLoss as composed in train_fully_supervised_2D_VIM.py:153-157 and
+ * train_Semi_Mamba_UNet.py:424-446.  logits (B, C, HW) in dtype (NCHW), labels (B, HW) integers of label_bytes (1, 4, 8);
+ * stats (3C+1) fp32 WRITTEN: [0,C) sum p_c*[y==c], [C,2C) sum [y==c], [2C,3C) sum p_c^2, [3C] sum -log p_y.
+ * workspace: ss2d_seg_loss_workspace_floats(C) floats.  Deterministic (fixed summation order, no atomics).
+ * _bwd: dlogits (same layout and dtype as logits, WRITTEN) from gstats = dL/dstats (3C+1, device):
+ * dlogit_c = p_c*(q_c - sum_k p_k q_k) + gstats[3C]*(p_c - [y==c]),  q_c = gstats[c]*[y==c] + 2*gstats[2C+c]*p_c.
+ * A label outside [0, C) contributes to no statistic (and gets no cross-entropy gradient).  C <= 16. */
+#define SS2D_SEG_LOSS_MAX_CLASSES 16
+size_t ss2d_seg_loss_workspace_floats(int C);
+int ss2d_seg_loss_stats(int dtype, const void *logits, const void *labels, int label_bytes, float *stats, float *workspace,
+                        int B, int C, long long HW, void *stream);
+int ss2d_seg_loss_bwd(int dtype, const void *logits, const void *labels, int label_bytes, const float *gstats, void *dlogits,
+                      int B, int C, long long HW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

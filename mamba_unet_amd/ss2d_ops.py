@@ -561,3 +561,54 @@ def ln_unshuffle_head(norm: torch.nn.Module, x: torch.Tensor, p: int, conv: torc
             and conv.out_channels <= 16):
         return _LNHead.apply(x, norm.weight, norm.bias, norm.eps, p, conv.weight)
     return conv(apply_norm_unshuffle(norm, x, p).permute(0, 3, 1, 2))
+
+
+class _SegLossStats(torch.autograd.Function):
+    """stats (3C+1) = [sum p_c*[y==c] | sum [y==c] | sum p_c^2 | sum -log p_y], p = softmax(logits, 1), in one pass
+    over the logits (csrc/ss2d_segloss.hip); the backward is one pass from dL/dstats.  Everything DiceLoss
+    (utils/losses.py:179-215) and nn.CrossEntropyLoss need of the (B, C, H, W) tensors."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, n_classes):
+        _need_gpu(logits, "seg_loss_stats")
+        _need_gpu(labels, "seg_loss_stats")
+        io, code = _io(logits)
+        if logits.dim() < 3 or logits.shape[1] != n_classes:
+            raise ValueError(f"seg_loss_stats: logits must be (B, {n_classes}, ...), got {tuple(logits.shape)}")
+        B, C = logits.shape[0], n_classes
+        HW = logits[0, 0].numel()
+        if labels.numel() != B * HW:
+            raise ValueError("predict & target shape do not match")          # the reference's assertion text (losses.py:205)
+        if labels.dtype not in (torch.uint8, torch.int32, torch.int64):
+            labels = labels.long()
+        lg = logits.to(io)
+        lg = lg if lg.is_contiguous() else lg.contiguous()
+        lb = labels if labels.is_contiguous() else labels.contiguous()
+        lib = _lib.load()
+        stats = torch.empty(3 * C + 1, device=lg.device, dtype=torch.float32)
+        ws = torch.empty(int(lib.ss2d_seg_loss_workspace_floats(C)), device=lg.device, dtype=torch.float32)
+        with torch.cuda.device(lg.device):
+            rc = lib.ss2d_seg_loss_stats(code, _lib.ptr(lg), _lib.ptr(lb), lb.element_size(), _lib.ptr(stats), _lib.ptr(ws),
+                                         B, C, HW, _stream())
+        _lib.check(rc, "ss2d_seg_loss_stats")
+        ctx.save_for_backward(lg, lb)
+        ctx.meta = (code, B, C, HW, logits.dtype)
+        return stats
+
+    @staticmethod
+    def backward(ctx, g):
+        lg, lb = ctx.saved_tensors
+        code, B, C, HW, in_dtype = ctx.meta
+        g32 = g.float().contiguous()
+        dl = torch.empty_like(lg)
+        with torch.cuda.device(lg.device):
+            rc = _lib.load().ss2d_seg_loss_bwd(code, _lib.ptr(lg), _lib.ptr(lb), lb.element_size(), _lib.ptr(g32), _lib.ptr(dl),
+                                               B, C, HW, _stream())
+        _lib.check(rc, "ss2d_seg_loss_bwd")
+        return dl.to(in_dtype), None, None
+
+
+def seg_loss_stats(logits: torch.Tensor, labels: torch.Tensor, n_classes: int) -> torch.Tensor:
+    """logits (B, C, H, W) fp32 / bf16, labels (B, H, W) or (B, 1, H, W) integers -> fp32 (3C+1):
+    [0, C) sum_{b,i} p_c [y == c], [C, 2C) sum [y == c], [2C, 3C) sum p_c^2, [3C] sum -log p_y.  Differentiable in logits."""
+    return _SegLossStats.apply(logits, labels, n_classes)

@@ -13,6 +13,7 @@ import torch
 import torch.nn.functional as F
 
 from .dist import all_reduce_sum
+from .ss2d_ops import seg_loss_stats
 
 
 def dice_loss(probs: torch.Tensor, target: torch.Tensor, n_classes: int, softmax: bool = False,
@@ -33,6 +34,26 @@ def dice_loss(probs: torch.Tensor, target: torch.Tensor, n_classes: int, softmax
     inter, ysum, zsum = stats
     smooth = 1e-5
     return (1.0 - (2 * inter + smooth) / (zsum + ysum + smooth)).mean()
+
+
+def ce_dice_from_stats(stats: torch.Tensor, n_pixels: int, n_classes: int, global_batch: bool = True):
+    """(mean cross entropy, Dice loss) from the (3C+1) statistics of `seg_loss_stats`: the same numbers as
+    nn.CrossEntropyLoss()(logits, y) and DiceLoss(C)(softmax(logits), y) (losses.py:192-215), of which only 13 (C = 4)
+    touch torch.  With `global_batch` the Dice sums are all-reduced across ranks (as in `dice_loss`); the cross entropy
+    stays the rank's own mean, which DistributedDataParallel's gradient average turns into the global mean."""
+    C = n_classes
+    ce = stats[3 * C] / n_pixels
+    if global_batch:
+        stats = all_reduce_sum(stats)
+    inter, ysum, zsum = stats[:C], stats[C:2 * C], stats[2 * C:3 * C]
+    smooth = 1e-5
+    return ce, (1.0 - (2 * inter + smooth) / (zsum + ysum + smooth)).mean()
+
+
+def ce_dice_loss(logits: torch.Tensor, labels: torch.Tensor, n_classes: int, global_batch: bool = True):
+    """(CE, Dice) of `logits` (B, C, H, W) against integer `labels` (B, H, W) through the fused statistics kernel."""
+    stats = seg_loss_stats(logits, labels, n_classes)
+    return ce_dice_from_stats(stats, logits.numel() // n_classes, n_classes, global_batch)
 
 
 def constra_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -56,7 +77,7 @@ class CapturableSGD:
         device = device or self.params[0].device
         self.param_groups = [{"lr": torch.tensor(float(lr), device=device), "momentum": momentum,
                               "weight_decay": weight_decay, "params": self.params}]
-        self.bufs = None
+        self.bufs = {}
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -70,14 +91,26 @@ class CapturableSGD:
         g = self.param_groups[0]
         ps = [p for p in self.params if p.grad is not None]
         d = torch._foreach_add([p.grad for p in ps], ps, alpha=g["weight_decay"])
-        if self.bufs is None:
-            self.bufs = {id(p): t.clone() for p, t in zip(ps, d)}
-            bufs = [self.bufs[id(p)] for p in ps]
-        else:
-            bufs = [self.bufs[id(p)] for p in ps]
-            torch._foreach_mul_(bufs, g["momentum"])
-            torch._foreach_add_(bufs, d)
+        # momentum buffers are created per parameter at its first gradient, as torch.optim.SGD does
+        old = [(p, t) for p, t in zip(ps, d) if id(p) in self.bufs]
+        for p, t in zip(ps, d):
+            if id(p) not in self.bufs:
+                self.bufs[id(p)] = t.clone()
+        if old:
+            ob = [self.bufs[id(p)] for p, _ in old]
+            torch._foreach_mul_(ob, g["momentum"])
+            torch._foreach_add_(ob, [t for _, t in old])
+        bufs = [self.bufs[id(p)] for p in ps]
         torch._foreach_sub_(ps, torch._foreach_mul(bufs, g["lr"]))
+
+    def state_dict(self):
+        """Momentum buffers by parameter position (the order of the constructor's `params`) and the learning rate."""
+        return {"lr": float(self.param_groups[0]["lr"]), "momentum_buffers": {i: self.bufs[id(p)].clone()
+                                                                              for i, p in enumerate(self.params) if id(p) in self.bufs}}
+
+    def load_state_dict(self, sd):
+        self.param_groups[0]["lr"].fill_(sd["lr"])
+        self.bufs = {id(self.params[int(i)]): t.clone().to(self.params[int(i)].device) for i, t in sd["momentum_buffers"].items()}
 
 
 def make_sgd(params, lr=0.01, tensor_lr_device=None):
@@ -104,9 +137,7 @@ def supervised_step(model, optimizer, images, labels, n_classes, it, max_it, bas
     .item() here: the reference syncs every iteration for tensorboard (:172-174), the caller decides."""
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast_bf16):
         out = model(images)
-    out = out.float()
-    loss_ce = F.cross_entropy(out, labels.long())
-    loss_dice = dice_loss(torch.softmax(out, dim=1), labels.unsqueeze(1), n_classes)
+    loss_ce, loss_dice = ce_dice_loss(out, labels, n_classes)     # softmax, CE and the Dice sums: one pass over the logits
     loss = 0.5 * (loss_dice + loss_ce)
     optimizer.zero_grad(set_to_none=True)
     loss.backward()
@@ -193,25 +224,34 @@ class GraphedForward:
         return self.out
 
 
-def semi_step(model1, model2, opt1, opt2, images, labels, labeled_bs, n_classes, it, max_it, consistency_weight,
-              base_lr=0.01):
-    """Cross pseudo supervision between two networks + ConstraLoss (train_Semi_Mamba_UNet.py:411-456)."""
-    o1, o2 = model1(images).float(), model2(images).float()
-    s1, s2 = torch.softmax(o1, dim=1), torch.softmax(o2, dim=1)
+def semi_loss(o1, o2, labels, labeled_bs, n_classes, consistency_weight):
+    """The loss of train_Semi_Mamba_UNet.py:414-446 from the two networks' logits: supervised 0.5*(CE + Dice) on the
+    labelled slices, Dice of each network's softmax against the OTHER network's argmax on the unlabelled slices
+    (argmax of the softmax = argmax of the logits), and ConstraLoss of the logits, counted once for each network."""
     lab = labels[:labeled_bs]
-    sup1 = 0.5 * (F.cross_entropy(o1[:labeled_bs], lab.long()) + dice_loss(s1[:labeled_bs], lab.unsqueeze(1), n_classes))
-    sup2 = 0.5 * (F.cross_entropy(o2[:labeled_bs], lab.long()) + dice_loss(s2[:labeled_bs], lab.unsqueeze(1), n_classes))
-    pseudo1 = torch.argmax(s1[labeled_bs:].detach(), dim=1)
-    pseudo2 = torch.argmax(s2[labeled_bs:].detach(), dim=1)
-    ps1 = dice_loss(s1[labeled_bs:], pseudo2.unsqueeze(1), n_classes)
-    ps2 = dice_loss(s2[labeled_bs:], pseudo1.unsqueeze(1), n_classes)
-    con = constra_loss(o1, o2)
-    loss = (sup1 + consistency_weight * ps1 + 0.5 * con) + (sup2 + consistency_weight * ps2 + 0.5 * con)
+    ce1, d1 = ce_dice_loss(o1[:labeled_bs], lab, n_classes)
+    ce2, d2 = ce_dice_loss(o2[:labeled_bs], lab, n_classes)
+    pseudo1 = torch.argmax(o1[labeled_bs:].detach(), dim=1)
+    pseudo2 = torch.argmax(o2[labeled_bs:].detach(), dim=1)
+    _, ps1 = ce_dice_loss(o1[labeled_bs:], pseudo2, n_classes)
+    _, ps2 = ce_dice_loss(o2[labeled_bs:], pseudo1, n_classes)
+    con = constra_loss(o1.float(), o2.float())
+    return (0.5 * (ce1 + d1) + consistency_weight * ps1 + 0.5 * con) + (0.5 * (ce2 + d2) + consistency_weight * ps2 + 0.5 * con)
+
+
+def semi_step(model1, model2, opt1, opt2, images, labels, labeled_bs, n_classes, it, max_it, consistency_weight,
+              base_lr=0.01, autocast_bf16=False):
+    """Cross pseudo supervision between two networks + ConstraLoss (train_Semi_Mamba_UNet.py:411-463).  `it` is the
+    0-based iteration: the reference increments iter_num BEFORE it evaluates the poly schedule (:458-461), so the
+    learning rate set here is poly_lr(it + 1) (the supervised script evaluates it before the increment)."""
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast_bf16):
+        o1, o2 = model1(images), model2(images)
+    loss = semi_loss(o1, o2, labels, labeled_bs, n_classes, consistency_weight)
     opt1.zero_grad(set_to_none=True)
     opt2.zero_grad(set_to_none=True)
     loss.backward()
     opt1.step()
     opt2.step()
     for opt in (opt1, opt2):
-        set_lr(opt, poly_lr(base_lr, it, max_it))
+        set_lr(opt, poly_lr(base_lr, it + 1, max_it))
     return loss.detach()

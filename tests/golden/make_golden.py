@@ -196,12 +196,97 @@ def config0_case(ref):
     print("config0", y.shape, float(y.abs().mean()))
 
 
+def vssm_grad_case(ref):
+    """Gradients of the whole network: the small VSSM of vssm_case (same seed and constructor, so vssm_small.npz holds
+    its state dict), eval mode (DropPath inert), batch 2, loss = sum(logits * g): logits, dx and the gradient of
+    EVERY parameter as the reference's autograd computes them on top of the sequential scan."""
+    ref.selective_scan_fn = selective_scan_ref
+    torch.manual_seed(1337)
+    m = ref.VSSM(patch_size=4, in_chans=3, num_classes=4, depths=[1, 1, 1, 1], dims=[16, 32, 64, 128],
+                 drop_path_rate=0.2).eval()
+    gen = torch.Generator().manual_seed(7)
+    x = torch.rand(2, 3, 32, 32, generator=gen).requires_grad_(True)
+    y = m(x)
+    g = torch.randn(y.shape, generator=gen)
+    (y * g).sum().backward()
+    out = {"x": np_(x), "g": np_(g), "logits": np_(y), "dx": np_(x.grad)}
+    for k, p in m.named_parameters():
+        out["grad." + k] = np_(p.grad)
+    np.savez_compressed(os.path.join(HERE, "vssm_small_grads.npz"), **out)
+    print("vssm_small_grads", y.shape, len(out))
+
+
+def unet_case():
+    """The reference's convolutional UNet (code/networks/unet.py:304-321; model1 of train_Semi_Mamba_UNet.py:302-303):
+    state-dict keys and shapes, and the eval-mode output of the seed-5 model on a fixed input (same seed -> same init)."""
+    spec = importlib.util.spec_from_file_location("ref_unet", "/root/reference/code/networks/unet.py")
+    U = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(U)
+    torch.manual_seed(5)
+    m = U.UNet(in_chns=1, class_num=4).eval()
+    x = torch.rand(2, 1, 32, 32, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        y = m(x)
+    sd = m.state_dict()
+    np.savez_compressed(os.path.join(HERE, "unet_ref.npz"), x=np_(x), y=np_(y), names=np.array(list(sd)),
+                        shapes=np.array([str(tuple(v.shape)) for v in sd.values()]))
+    print("unet_ref", y.shape, len(sd))
+
+
+def losses_case():
+    """The reference's own loss code (code/utils/losses.py: DiceLoss, ConstraLoss) composed exactly as its scripts do:
+    supervised  0.5 * (CE + Dice(softmax))            train_fully_supervised_2D_VIM.py:153-157
+    semi        cross pseudo supervision + ConstraLoss train_Semi_Mamba_UNet.py:414-446
+    on fixed random logits: loss values and the gradients w.r.t. the logits."""
+    spec = importlib.util.spec_from_file_location("ref_losses", "/root/reference/code/utils/losses.py")
+    L = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(L)
+    out = {}
+    gen = torch.Generator().manual_seed(11)
+    for tag, (B, C, S) in {"sup4": (3, 4, 16), "sup9": (2, 9, 12)}.items():
+        logits = (2.0 * torch.randn(B, C, S, S, generator=gen)).requires_grad_(True)
+        labels = torch.randint(0, C, (B, S, S), generator=gen)
+        ce, dice = nn.CrossEntropyLoss(), L.DiceLoss(C)
+        soft = torch.softmax(logits, dim=1)
+        loss = 0.5 * (dice(soft, labels.unsqueeze(1)) + ce(logits, labels.long()))
+        loss.backward()
+        out.update({f"{tag}.logits": np_(logits), f"{tag}.labels": labels.numpy().astype(np.uint8), f"{tag}.loss": np_(loss),
+                    f"{tag}.dlogits": np_(logits.grad)})
+    B, C, S, lb, cw = 4, 4, 16, 2, 0.37
+    o1 = (2.0 * torch.randn(B, C, S, S, generator=gen)).requires_grad_(True)
+    o2 = (2.0 * torch.randn(B, C, S, S, generator=gen)).requires_grad_(True)
+    labels = torch.randint(0, C, (B, S, S), generator=gen)
+    ce, dice = nn.CrossEntropyLoss(), L.DiceLoss(C)
+    s1, s2 = torch.softmax(o1, dim=1), torch.softmax(o2, dim=1)
+    loss1 = 0.5 * (ce(o1[:lb], labels[:lb].long()) + dice(s1[:lb], labels[:lb].unsqueeze(1)))
+    loss2 = 0.5 * (ce(o2[:lb], labels[:lb].long()) + dice(s2[:lb], labels[:lb].unsqueeze(1)))
+    p1 = torch.argmax(s1[lb:].detach(), dim=1, keepdim=False)
+    p2 = torch.argmax(s2[lb:].detach(), dim=1, keepdim=False)
+    ps1, ps2 = dice(s1[lb:], p2.unsqueeze(1)), dice(s2[lb:], p1.unsqueeze(1))
+    con1 = L.ConstraLoss(o1, o2)
+    loss = (loss1 + cw * ps1 + 0.5 * con1) + (loss2 + cw * ps2 + 0.5 * con1)
+    loss.backward()
+    out.update({"semi.o1": np_(o1), "semi.o2": np_(o2), "semi.labels": labels.numpy().astype(np.uint8), "semi.loss": np_(loss),
+                "semi.do1": np_(o1.grad), "semi.do2": np_(o2.grad), "semi.labeled_bs": np.array(lb), "semi.consistency_weight": np.array(cw)})
+    np.savez_compressed(os.path.join(HERE, "losses.npz"), **out)
+    print("losses", {k: float(v) for k, v in out.items() if k.endswith(".loss")})
+
+
 if __name__ == "__main__":
     import sys
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "losses":
+        losses_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "unet":
+        unet_case()
+        sys.exit(0)
     ref = load_reference()
     if len(sys.argv) > 1 and sys.argv[1] == "config0":     # add this fixture without rewriting the others
         config0_case(ref)
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vssm_grads":
+        vssm_grad_case(ref)
         sys.exit(0)
     index_tables(ref)
     ss2d_case(ref, "ss2d_2x8x5x7_s0.npz", 2, 8, 5, 7, seed=0, with_scan_args=True)
@@ -209,3 +294,6 @@ if __name__ == "__main__":
     ss2d_case(ref, "ss2d_2x96x14x14_s0.npz", 2, 96, 14, 14, seed=0, with_scan_args=False)
     vssm_case(ref)
     config0_case(ref)
+    vssm_grad_case(ref)
+    losses_case()
+    unet_case()

@@ -109,3 +109,35 @@ def test_capturable_sgd_matches_torch_sgd():
             set_lr(o, 0.01 * (1 - it / 10) ** 0.9)
     for x, y in zip(a, b):
         assert torch.allclose(x, y, rtol=1e-6, atol=1e-7)
+
+
+def test_unet_model1_matches_reference_keys_and_output():
+    """UNet (model1 of the semi configuration): same state-dict keys / shapes and, from the same seed, the same
+    eval-mode output as the reference's networks/unet.py (tests/golden/unet_ref.npz)."""
+    import numpy as np
+    from mamba_unet_amd.unet import UNet
+    g = np.load(os.path.join(GOLDEN, "unet_ref.npz"))
+    torch.manual_seed(5)
+    m = UNet(in_chns=1, class_num=4).eval()
+    sd = m.state_dict()
+    assert list(sd) == list(g["names"]) and [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["x"]))
+    assert torch.allclose(y, torch.from_numpy(g["y"]), atol=1e-6)
+
+
+def test_ce_dice_from_stats_reproduces_reference_losses():
+    """The 13-number half of the fused loss (train.ce_dice_from_stats) on statistics summed here in torch, against the
+    loss values of the reference's own DiceLoss + CrossEntropyLoss (tests/golden/losses.npz)."""
+    import numpy as np
+    from mamba_unet_amd.train import ce_dice_from_stats
+    g = np.load(os.path.join(GOLDEN, "losses.npz"))
+    for tag in ("sup4", "sup9"):
+        logits, labels = torch.from_numpy(g[tag + ".logits"]).double(), torch.from_numpy(g[tag + ".labels"]).long()
+        C = logits.shape[1]
+        p = torch.softmax(logits, 1)
+        oh = (labels.unsqueeze(1) == torch.arange(C).view(1, -1, 1, 1)).double()
+        ce = -(torch.log_softmax(logits, 1) * oh).sum()
+        stats = torch.cat([(p * oh).sum((0, 2, 3)), oh.sum((0, 2, 3)), (p * p).sum((0, 2, 3)), ce.view(1)])
+        ce_m, dice = ce_dice_from_stats(stats, logits.numel() // C, C, global_batch=False)
+        assert abs(float(0.5 * (ce_m + dice)) - float(g[tag + ".loss"])) < 1e-6
