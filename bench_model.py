@@ -42,8 +42,7 @@ def main():
                     help="A/B: run cross_scan / scan / cross_merge literally (4 materialised directions) instead of the fused-direction path")
     ap.add_argument("--graph", action="store_true",
                     help="1 GPU.  infer: replay the forward from a HIP graph (checked against eager at capture).  train: "
-                         "whole-step capture, experimental: refused unless SS2D_ALLOW_HIP_GRAPH=1, torch's reductions "
-                         "replay wrongly on this stack; not a number of record")
+                         "the whole step (forward, loss, backward, SGD) captured once and replayed")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)

@@ -249,6 +249,12 @@ int ss2d_ln_head_bwd(int in_dtype, int out_dtype, const void *dlogits, const voi
  * _bwd: dlogits (same layout and dtype as logits, WRITTEN) from gstats = dL/dstats (3C+1, device):
  * dlogit_c = p_c*(q_c - sum_k p_k q_k) + gstats[3C]*(p_c - [y==c]),  q_c = gstats[c]*[y==c] + 2*gstats[2C+c]*p_c.
  * A label outside [0, C) contributes to no statistic (and gets no cross-entropy gradient).  C <= 16. */
+/* Column sums out[j] = sum_r x[r*ldx + j] (fp32) of a (rows, M) matrix in dtype: autograd's bias gradient of the Linears
+ * that have a bias (`concat_back_dim`, mamba_sys.py:774-778, applied :835).  Deterministic (per-workgroup partial rows in
+ * `workspace`, ss2d_colsum_workspace_floats(M) floats, added in a fixed order); out is WRITTEN. */
+size_t ss2d_colsum_workspace_floats(int M);
+int ss2d_colsum(int dtype, const void *x, float *out, float *workspace, long long rows, int M, long long ldx, void *stream);
+
 #define SS2D_SEG_LOSS_MAX_CLASSES 16
 size_t ss2d_seg_loss_workspace_floats(int C);
 int ss2d_seg_loss_stats(int dtype, const void *logits, const void *labels, int label_bytes, float *stats, float *workspace,

@@ -167,6 +167,24 @@ def linear_wgrad(grad_out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
     return dw
 
 
+def colsum(g: torch.Tensor) -> torch.Tensor:
+    """fp32 sum over all leading axes of g[..., M] (a Linear's bias gradient), csrc/ss2d_colsum.hip: deterministic, and
+    unlike torch's multi-block reduction it replays correctly inside a captured HIP graph."""
+    _need_gpu(g, "colsum")
+    io, code = _io(g)
+    M = g.shape[-1]
+    g2 = g.reshape(-1, M).to(io)
+    if g2.stride(1) != 1:
+        g2 = g2.contiguous()
+    lib = _lib.load()
+    out = torch.empty(M, device=g.device, dtype=torch.float32)
+    ws = torch.empty(int(lib.ss2d_colsum_workspace_floats(M)), device=g.device, dtype=torch.float32)
+    with torch.cuda.device(g.device):
+        rc = lib.ss2d_colsum(code, _lib.ptr(g2), _lib.ptr(out), _lib.ptr(ws), g2.shape[0], M, g2.stride(0), _stream())
+    _lib.check(rc, "ss2d_colsum")
+    return out
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T (+ b) for the Linears whose token axis dwarfs both feature axes: forward and dX stay on
     hipBLASLt (F.linear / matmul, good shapes), dW goes to the split-token MFMA kernel, db is a column sum."""
@@ -192,8 +210,57 @@ class _Linear(torch.autograd.Function):
         dw = linear_wgrad(g, x).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
-            db = g.reshape(-1, g.shape[-1]).sum(0, dtype=torch.float32).to(ctx.b_dtype)
+            db = colsum(g).to(ctx.b_dtype)
         return dx, dw, db
+
+
+class _ConcatLinear(torch.autograd.Function):
+    """y = cat([x, skip], -1) W^T + b without the concatenated tensor (the decoder's skip connection,
+    mamba_sys.py:835): W = [W1 | W2], y = x W1^T + b, then y += skip W2^T accumulated in place by the second GEMM.
+    Backward: dx = g W1, dskip = g W2 (no split of a concatenated gradient), dW from the MFMA weight-gradient kernel for
+    each half, db from `colsum`."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias):
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            x, skip, w = x.to(dt), skip.to(dt), weight.to(dt)
+            b = None if bias is None else bias.to(dt)
+        else:
+            w, b = weight, bias
+            skip = skip.to(x.dtype)
+        C1 = x.shape[-1]
+        ctx.save_for_backward(x, skip, w)
+        ctx.w_dtype, ctx.b_dtype = weight.dtype, None if bias is None else bias.dtype
+        with torch.autocast("cuda", enabled=False):
+            y = torch.nn.functional.linear(x, w[:, :C1], b)
+            y.view(-1, y.shape[-1]).addmm_(skip.reshape(-1, skip.shape[-1]), w[:, C1:].t())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, skip, w = ctx.saved_tensors
+        g = g.to(x.dtype)
+        C1 = x.shape[-1]
+        dx = torch.matmul(g, w[:, :C1]) if ctx.needs_input_grad[0] else None
+        dskip = torch.matmul(g, w[:, C1:]) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[2]:
+            rows, M = g.numel() // g.shape[-1], g.shape[-1]
+            if rows >= 32 * min(M, C1):
+                dw = torch.cat([linear_wgrad(g, x), linear_wgrad(g, skip)], dim=1).to(ctx.w_dtype)
+            else:
+                g2 = g.reshape(-1, M)
+                dw = torch.cat([g2.t() @ x.reshape(rows, -1), g2.t() @ skip.reshape(rows, -1)], dim=1).to(ctx.w_dtype)
+        db = colsum(g).to(ctx.b_dtype) if (ctx.b_dtype is not None and ctx.needs_input_grad[3]) else None
+        return dx, dskip, dw, db
+
+
+def concat_linear(module: torch.nn.Module, x: torch.Tensor, skip: torch.Tensor) -> torch.Tensor:
+    """module(torch.cat([x, skip], -1)) for an nn.Linear, without materialising the concatenation."""
+    if type(module) is torch.nn.Linear and x.is_cuda and module.in_features == x.shape[-1] + skip.shape[-1] and x.shape[:-1] == skip.shape[:-1]:
+        return _ConcatLinear.apply(x, skip, module.weight, module.bias)
+    return apply_linear(module, torch.cat([x, skip], dim=-1))
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:

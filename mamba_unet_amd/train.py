@@ -152,19 +152,14 @@ class GraphedSupervisedStep:
     captured here).  Inputs are copied into static buffers; the learning rate must be a device tensor
     (make_sgd(..., tensor_lr_device=dev)).
 
-    NOT USABLE on the ROCm 7.0 / PyTorch 2.10 stack of this image, and refused unless SS2D_ALLOW_HIP_GRAPH=1: from
-    the second replay on, torch's multi-block reduction kernels (`x.sum((0, 2, 3))` of the Dice statistics, the row
-    sums of bias gradients) return wrong sums -- the first of several reductions in a graph is right, the later
-    ones are not (scratch/graph_dice.py isolates it: no kernel of this package involved; every op of this package
-    replays bit-exactly, scratch/graph_ops.py).  The training loss then drifts and goes NaN within ~6 replays.
-    The eager step is GPU-bound since the fusions (26.8 ms eager vs 26.7 ms replayed), so nothing is lost."""
+    History: on this ROCm 7.0 / PyTorch 2.10 stack torch's multi-block reduction kernels return wrong sums from the
+    second replay of a captured graph on (tools/graph_dice_repro.py shows it with torch ops alone: the second and third
+    `x.sum((0, 2, 3))` of a graph go wrong).  The step used to contain two kinds of them -- the Dice statistics and the
+    bias-gradient row sums of the skip-connection Linears -- and its replays drifted to NaN.  Both are kernels of this
+    package now (ss2d_seg_loss_stats, ss2d_colsum), and ten replays reproduce ten eager steps to the last bit of the
+    loss (tests/test_configs_gpu.py::test_graphed_supervised_step_matches_eager, tools/graph_vs_eager.py)."""
 
     def __init__(self, model, optimizer, images, labels, n_classes, max_it, base_lr=0.01, autocast_bf16=False, warmup=3):
-        import os
-        if not os.environ.get("SS2D_ALLOW_HIP_GRAPH"):
-            raise RuntimeError("GraphedSupervisedStep: HIP-graph replay of torch's reduction kernels returns wrong sums on "
-                               "this ROCm/PyTorch stack (see the class docstring); use supervised_step, or set "
-                               "SS2D_ALLOW_HIP_GRAPH=1 to experiment")
         self.opt, self.max_it, self.base_lr = optimizer, max_it, base_lr
         self.images, self.labels = images.clone(), labels.clone()
         args = (model, optimizer, self.images, self.labels, n_classes)

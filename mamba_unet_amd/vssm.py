@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .ss2d import VSSLayer, VSSLayer_up
-from .ss2d_ops import apply_linear, apply_norm, apply_norm_unshuffle, ln_unshuffle_head
+from .ss2d_ops import apply_linear, apply_norm, apply_norm_unshuffle, concat_linear, ln_unshuffle_head
 
 
 class PatchEmbed2D(nn.Module):
@@ -153,7 +153,7 @@ class VSSM(nn.Module):
     def forward_up_features(self, x, x_downsample):
         for i, up in enumerate(self.layers_up):
             if i > 0:
-                x = apply_linear(self.concat_back_dim[i], torch.cat([x, x_downsample[3 - i]], dim=-1))
+                x = concat_linear(self.concat_back_dim[i], x, x_downsample[3 - i])       # mamba_sys.py:835 without the cat
             x = up(x)
         return apply_norm(self.norm_up, x)
 

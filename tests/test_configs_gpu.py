@@ -133,3 +133,35 @@ def test_config0_bf16_logits_against_reference_fp32_golden():
         y = net(torch.from_numpy(g["x"]).cuda())
     err = rel_l2(y.float().cpu(), g["logits"])
     assert err < 2e-2, err       # bf16 storage through 14 SS2D blocks (measured ~5e-3); per-op gate is 1e-2 (tests/test_bf16_gpu.py)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_graphed_supervised_step_matches_eager(bf16):
+    """The whole training iteration captured in a HIP graph (train.GraphedSupervisedStep): ten replays against ten eager
+    steps of an identical copy, loss within 1e-6 relative at every step in fp32.  Under bf16 autocast two EAGER runs already
+    differ by ~2e-5: the float-atomic sums of the weight gradients change in the last bit from run to run and bf16
+    re-rounding amplifies that; the gate there is 1e-3 (a mis-replayed reduction shows up as a loss off by percents and NaN
+    within a few steps)."""
+    import copy
+    from mamba_unet_amd import SS2D, MambaUnet
+    from mamba_unet_amd.train import GraphedSupervisedStep, make_sgd, supervised_step
+    SS2D.bf16_scan_io = bf16
+    torch.manual_seed(1337)
+    net1 = MambaUnet(img_size=224, num_classes=4).cuda().train()
+    for m in net1.modules():                 # DropPath draws from the generator: eager and captured would see other masks
+        if hasattr(m, "drop_prob"):
+            m.drop_prob = 0.0
+    net2 = copy.deepcopy(net1)
+    gen = torch.Generator().manual_seed(9)
+    images = torch.rand(4, 1, 224, 224, generator=gen).cuda()
+    labels = torch.randint(0, 4, (4, 224, 224), generator=gen).to(torch.uint8).cuda()
+    dev = torch.device("cuda")
+    opt1, opt2 = make_sgd(net1.parameters(), tensor_lr_device=dev), make_sgd(net2.parameters(), tensor_lr_device=dev)
+    warm = 3
+    gstep = GraphedSupervisedStep(net1, opt1, images, labels, 4, 10000, autocast_bf16=bf16, warmup=warm)
+    for i in range(warm):                   # the constructor ran `warm` eager steps (capturing executes nothing)
+        supervised_step(net2, opt2, images, labels, 4, i, 10000, autocast_bf16=bf16)
+    for k in range(10):
+        lg = float(gstep(gstep.images, gstep.labels, warm + k))
+        le = float(supervised_step(net2, opt2, images, labels, 4, warm + k, 10000, autocast_bf16=bf16))
+        assert abs(lg - le) <= (1e-3 if bf16 else 1e-6) * abs(le), (k, lg, le)

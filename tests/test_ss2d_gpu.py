@@ -419,3 +419,38 @@ def test_graphed_forward_matches_eager():
     with torch.no_grad():
         want = net(x1)
     assert torch.equal(g(x1), want)
+
+
+@pytest.mark.parametrize("rows,M,ldx,dtype", [(5000, 96, 96, torch.float32), (75264, 96, 96, torch.bfloat16), (777, 33, 40, torch.float32),
+                                              (1, 768, 768, torch.float32), (4704, 384, 384, torch.bfloat16)])
+def test_colsum_matches_fp64(rows, M, ldx, dtype):
+    from mamba_unet_amd.ss2d_ops import colsum
+    gen = torch.Generator().manual_seed(rows + M)
+    wide = torch.randn(rows, ldx, generator=gen).to(dtype)
+    got = colsum(wide.cuda()[:, :M])
+    assert got.dtype == torch.float32 and rel_l2(got.cpu(), wide[:, :M].double().sum(0)) < 1e-5
+    assert torch.equal(got, colsum(wide.cuda()[:, :M]))          # deterministic
+
+
+@pytest.mark.parametrize("B,H,W,C,dtype", [(2, 56, 56, 96, torch.float32), (2, 14, 14, 384, torch.float32), (3, 28, 28, 192, torch.bfloat16)])
+def test_concat_linear_matches_cat_then_linear(B, H, W, C, dtype):
+    """The decoder's skip connection (mamba_sys.py:835): Linear(cat([x, skip])) without the concatenated tensor."""
+    from mamba_unet_amd.ss2d_ops import concat_linear
+    gen = torch.Generator().manual_seed(C)
+    lin = torch.nn.Linear(2 * C, C)
+    x, skip = torch.randn(B, H, W, C, generator=gen).to(dtype), torch.randn(B, H, W, C, generator=gen).to(dtype)
+    g = torch.randn(B, H, W, C, generator=gen).to(dtype)
+    ref = torch.nn.Linear(2 * C, C).double()
+    ref.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    xr, sr = x.double().requires_grad_(True), skip.double().requires_grad_(True)
+    yr = ref(torch.cat([xr, sr], -1))
+    yr.backward(g.double())
+    lin = lin.cuda()
+    xd, sd = x.cuda().requires_grad_(True), skip.cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+        y = concat_linear(lin, xd, sd)
+    y.backward(g.cuda())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(y.detach().float().cpu(), yr.detach()) < tol
+    assert rel_l2(xd.grad.float().cpu(), xr.grad) < tol and rel_l2(sd.grad.float().cpu(), sr.grad) < tol
+    assert rel_l2(lin.weight.grad.cpu(), ref.weight.grad) < tol and rel_l2(lin.bias.grad.cpu(), ref.bias.grad) < tol
