@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--atomic-dbc", action="store_true", help="dB/dC through float atomics (no workspace): the round-1 form")
+    ap.add_argument("--no-model", action="store_true", help="skip the MambaUNet training-step leg (second half of BASELINE.json's metric)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -186,6 +187,23 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * (fb + bb) / (elapsed / args.steps) / 1e9
 
+    # ---- second half of BASELINE.json's metric: MambaUNet train slices/s at 224x224 (configs[2]: batch 24 per GPU, bf16,
+    # DDP over RCCL when N > 1), outside the timed region of the headline value; same barrier + max-over-ranks timing
+    model = None
+    if not args.no_model:
+        import bench_model
+        margs = bench_model.parser().parse_args(["--mode", "train", "--dtype", "bf16", "--steps", "20", "--warmup", "5"])
+        try:
+            model = bench_model.run(margs, rank, world, local, dist)
+        except Exception as e:      # the headline line must survive a failure of the secondary leg; it is reported, not hidden
+            model = {"error": f"{type(e).__name__}: {e}"[:300]} if rank == 0 else None
+        if model is not None and "error" not in model:
+            # SURVEY.md 8(d) "whole-model algorithmic scan bytes": 584.2 MB per slice fwd+bwd in fp32, half of it with bf16 I/O
+            scan_bytes = 0.5 * 584.2e6 * margs.batch
+            model = {k: model[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "peak_mem_GB", "valid")}
+            model["scan_algorithmic_GBs_per_gpu"] = round(scan_bytes / (model["ms_per_step"] * 1e-3) / 1e9, 1)
+            model["frac_of_hbm_peak_scan_bytes_only"] = round(model["scan_algorithmic_GBs_per_gpu"] / HBM_PEAK_GBS, 4)
+
     if rank == 0:
         # parity spot check of what was just timed (slice 0) + CPU baseline, N=1 only
         cpu = None
@@ -228,7 +246,7 @@ def main():
             "frac_of_hbm_peak_fwd_bwd": round(value / world / HBM_PEAK_GBS, 4),
             "kernels_us": {"scan_fwd": round(fwd_us, 2), "scan_bwd": round(bwd_us, 2),
                            "fwd_GBs": round(fb / fwd_us / 1e3, 1), "bwd_GBs": round(bb / bwd_us / 1e3, 1)},
-            "cpu_baseline": cpu, "parity_rel_l2_vs_cpu_oracle": parity,
+            "cpu_baseline": cpu, "parity_rel_l2_vs_cpu_oracle": parity, "mambaunet_train": model,
         }
         print(json.dumps(line))
     if dist is not None:

@@ -29,7 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", choices=["train", "infer", "semi"], default="train")
     ap.add_argument("--model1", choices=["unet", "vim"], default="unet", help="semi mode: the first network (reference default: unet)")
@@ -46,18 +46,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    args = ap.parse_args()
+    return ap
 
+
+def main():
+    args = parser().parse_args()
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    line = run(args, rank, world, local, dist)
+    if rank == 0:
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
 
+
+def run(args, rank, world, local, dist):
+    """One measurement (bench.py calls this too, for the model-level half of BASELINE.json's metric).  Returns the JSON
+    record on rank 0, None elsewhere.  `dist` is the initialised torch.distributed module or None."""
+    dev = torch.device("cuda", local)
     from mamba_unet_amd import MambaUnet
     from mamba_unet_amd.dist import wrap_ddp
     from mamba_unet_amd.train import GraphedSupervisedStep, make_sgd, semi_step, supervised_step
@@ -130,10 +142,12 @@ def main():
         elapsed = float(t.item())
     finite = bool(torch.isfinite(last.float()).all())
 
+    from mamba_unet_amd import SS2D as _SS2D
+    _SS2D.bf16_scan_io, _SS2D.fused_directions = False, True          # class-wide switches back to their defaults
     if rank == 0:
         if not finite:
             print("bench_model.py: WARNING: the last step's output is not finite -- this run is not a valid measurement", file=sys.stderr)
-        print(json.dumps({
+        return ({
             "metric": f"MambaUNet {args.mode} slices/s @{args.size}x{args.size}",
             "value": round(world * args.batch * args.steps / elapsed, 2), "unit": "slices/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -144,9 +158,8 @@ def main():
                                    f"{args.batch} per GPU, {args.size}x{args.size}, {args.classes} classes",
                        "parallelism": f"DDP x{world} (batch-sharded slices, RCCL gradient all-reduce)"},
             "hip_graph": bool(args.graph and world == 1 and args.mode in ("train", "infer")),
-            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "finite": finite, "valid": finite}))
-    if dist is not None:
-        dist.destroy_process_group()
+            "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2), "finite": finite, "valid": finite})
+    return None
 
 
 if __name__ == "__main__":

@@ -70,9 +70,10 @@ def all_reduce_sum(x: torch.Tensor) -> torch.Tensor:
 
 def wrap_ddp(model: torch.nn.Module, local_rank: int | None = None):
     """DistributedDataParallel with the settings SURVEY.md 5 derives: every parameter gets a gradient each
-    step (find_unused_parameters=False), buckets are views (one less copy of the 76.5 MB gradient)."""
+    step (find_unused_parameters=False, static_graph=True), buckets are views (one less copy of the 76.5 MB gradient)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [local_rank] if (local_rank is not None and next(model.parameters()).is_cuda) else None
-    return DDP(model, device_ids=ids, gradient_as_bucket_view=True, find_unused_parameters=False)
+    # static_graph: the set of used parameters and the order of their gradients never change between iterations
+    return DDP(model, device_ids=ids, gradient_as_bucket_view=True, find_unused_parameters=False, static_graph=True)
