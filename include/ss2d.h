@@ -119,6 +119,23 @@ int ss2d_selective_scan_dir_bwd_static(int dtype, const void *u, const void *del
                                        int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask,
                                        long long bc_bg_stride, void *stream);
 
+/* dt_proj folded into the scan (mamba_sys.py:417-424 + :436-442): the (batch, K*D, L) `delta` tensor
+ * is never materialised.  x_dbl (batch, ngroups, dt_rank + 2*dstate, L) is the x_proj output with rows [dts | B | C] per
+ * (batch, group) block, read in place three times; dt_w (dim, dt_rank) fp32 (= dt_projs_weight (K, D, R) in scan-group
+ * order): delta[b, d, l] = sum_r dt_w[d, r] * dts[b, g(d), r, l], then softplus(delta + delta_bias[d]) as in SS2D.
+ * Other arguments as ss2d_selective_scan_dir_fwd / _bwd_ws (delta_softplus = 1, no z, dstate == 16, L % 4 == 0,
+ * dt_rank <= SS2D_MAX_DT_RANK; the backward needs dt_rank 6 or 12 and a workspace).  _bwd still WRITES ddelta
+ * (batch, dim, L): the gradients of dt_w and of the dts rows are its contractions with dts / dt_w (caller). */
+#define SS2D_MAX_DT_RANK 16
+int ss2d_selective_scan_core_fwd(int dtype, const void *u, const void *x_dbl, const float *dt_w, const float *A, const float *D,
+                                 const float *delta_bias, void *out, float *ckpt, int batch, int dim, int L, int dstate,
+                                 int ngroups, int dt_rank, int u_groups, unsigned rev_mask, void *stream);
+int ss2d_selective_scan_core_bwd(int dtype, const void *u, const void *x_dbl, const float *dt_w, const float *A, const float *D,
+                                 const float *delta_bias, const void *dout, const float *ckpt, void *du, void *ddelta, float *dA,
+                                 float *dB, float *dC, float *dD, float *ddelta_bias, int batch, int dim, int L, int dstate,
+                                 int ngroups, int dt_rank, int u_groups, unsigned rev_mask, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+
 /* CrossScan (mamba_sys.py:403-404): x (B, D, H, W) -> xs (B, 4, D, H*W); _bwd is its adjoint
  * (sums the four directions back into dx). */
 int ss2d_cross_scan_fwd(int dtype, const void *x, void *xs, int B, int D, int H, int W, void *stream);

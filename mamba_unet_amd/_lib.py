@@ -24,6 +24,8 @@ _SIGNATURES = {
     "ss2d_scan_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
     "ss2d_selective_scan_dir_bwd_ws": (_i, [_i] + [_vp] * 18 + [_i] * 7 + [ctypes.c_uint, ctypes.c_longlong, _vp, _sz, _vp]),
     "ss2d_selective_scan_dir_bwd_static": (_i, [_i] + [_vp] * 18 + [_i] * 7 + [ctypes.c_uint, ctypes.c_longlong, _vp]),
+    "ss2d_selective_scan_core_fwd": (_i, [_i] + [_vp] * 8 + [_i] * 7 + [ctypes.c_uint, _vp]),
+    "ss2d_selective_scan_core_bwd": (_i, [_i] + [_vp] * 15 + [_i] * 7 + [ctypes.c_uint, _vp, _sz, _vp]),
     "ss2d_cross_scan_fwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ss2d_cross_scan_bwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ss2d_cross_merge_fwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -14,6 +14,8 @@ struct ScanBwdParams {
     long long bc_stride; // elements between consecutive (batch, group) blocks of B and of C (N*L when dense); dB/dC are dense
     int rows_per_wg;     // state-row kernel: (batch, channel) rows per workgroup
     float *ws;           // state-row kernel: partial dB/dC tiles (one per workgroup and (batch, group) it touches), or null = atomics
+    const float *dtw;    // fused-delta form (null otherwise): dt_proj weight (dim, R); `delta` then points at the dts rows (R, L) of
+    int R;               // every (batch, group) block (block stride bc_stride) and delta = dtw . dts is recomputed in the kernel
 };
 
 // The state-row backward (ss2d_scan_bwd_sr.hip): dstate == 16, no z.  Returns a hipError_t / 0.

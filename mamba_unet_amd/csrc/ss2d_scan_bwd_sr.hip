@@ -57,7 +57,10 @@ __device__ unsigned long long *g_sr_probe;
 #define SR_PROBE(i) do { } while (0)
 #endif
 
-template <bool VEC, typename IO, bool DIRS, bool WS>
+// DTR > 0: the fused-delta form (ss2d_selective_scan_core_bwd): p.delta points at the rank-DTR dts rows of the x_proj output
+// and delta[c, l] = sum_r dtw[c, r] * dts[r, l] is recomputed for the lane's two positions (2*DTR FMAs per channel-chunk);
+// the dts values of a chunk stay in 2*DTR registers, the weight row of a channel arrives through scalar loads.
+template <bool VEC, typename IO, bool DIRS, bool WS, int DTR = 0>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_bwd_sr_kernel(const ScanBwdParams p) {
     extern __shared__ __align__(16) float smem[];
 #ifdef SS2D_SR_PROBE
@@ -130,14 +133,31 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 hi4[m] = buf_load4m<VEC, IO>(rs, (unsigned)(2 * tnp + 1) * L, pos, L, rev);
             }
         };
-        f2 nu, nd, ny;
+        f2 nu, nd = f2{0.0f, 0.0f}, ny;
         f4 nAv, nck;
         float nbias, nD;
+        constexpr int NR = DTR > 0 ? DTR : 1;
+        float nw[NR];                                  // DTR: dt_proj weight row of the next channel (wave-uniform: scalar registers)
+        f2 dtsv[NR];                                   // DTR: dts[r] at this lane's two positions of the current chunk
+        typedef const float __attribute__((address_space(4))) *cfp;
         auto input_load = [&](int k_, int chunk_) {
             const int ps_ = chunk_ * CHUNK + 8 * seg + 2 * row;
             nu = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.u) + (urow0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
-            nd = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.delta) + (r0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
+            if (DTR == 0) nd = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.delta) + (r0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
             ny = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.dout) + (urow0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
+            if (DTR > 0) {
+                const cfp wp = (cfp)(uintptr_t)(p.dtw + (size_t)(cdim0 + k_) * DTR);
+#pragma unroll
+                for (int r = 0; r < NR; ++r) nw[r] = wp[r];
+            }
+        };
+        auto dts_load = [&](int chunk_) {             // DTR: the chunk's dts values of this lane (all channels of the part share them)
+            if (DTR > 0) {
+                const int ps_ = chunk_ * CHUNK + 8 * seg + 2 * row;
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    dtsv[r] = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.delta) + (size_t)bg * bcs + (size_t)r * L, rowbytes), ps_, L, rev);
+            }
         };
         auto param_load = [&](int k_, int chunk_) {
             const int c_ = cdim0 + k_;
@@ -148,6 +168,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         };
         f4 tlo[NM], thi[NM];
         tile_load(nchunks - 1, tlo, thi);
+        dts_load(nchunks - 1);
         input_load(kfirst, nchunks - 1);
         param_load(kfirst, nchunks - 1);
 
@@ -188,7 +209,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const bool lastk = kt >= n;
                 const int kn = lastk ? kfirst : kt, chn = lastk ? chunk_next : chunk;
                 if (lane == 0) tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                const f2 cu = nu, cd = nd, cy = ny;
+                const f2 cu = nu, cy = ny;
+                f2 cd = nd;
+                if (DTR > 0) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) cd = fma2(splat2(nw[r]), dtsv[r], cd);
+                }
                 const f4 Av = nAv, ck = nck;
                 const float bias = has_bias ? nbias : 0.0f, Dc = has_D ? nD : 0.0f;
                 input_load(kn, chn);
@@ -352,6 +378,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 kt = kt2;
             }
             tile_load(chunk_next, tlo, thi);   // arrives during the flush
+            dts_load(chunk_next);
 
             SR_PROBE(11);
             __syncthreads();   // every wave is done with the tile
@@ -440,9 +467,9 @@ __global__ __launch_bounds__(256) void scan_bwd_sr_reduce_kernel(const float *__
     *reinterpret_cast<f4 *>(dst) = acc;
 }
 
-template <bool VEC, typename IO, bool DIRS, bool WS>
+template <bool VEC, typename IO, bool DIRS, bool WS, int DTR = 0>
 int launch_sr(const ScanBwdParams &p, int nwg, hipStream_t s) {
-    auto kern = scan_bwd_sr_kernel<VEC, IO, DIRS, WS>;
+    auto kern = scan_bwd_sr_kernel<VEC, IO, DIRS, WS, DTR>;
     static bool attr_set[SS2D_MAX_DEVICES] = {};   // per instantiation and device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SS2D_MAX_DEVICES) dev = 0;
@@ -525,7 +552,12 @@ int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, fl
     p.ws = (ws && (p.L % 4 == 0) && (((uintptr_t)ws | (uintptr_t)p.dB | (uintptr_t)p.dC) & 15) == 0 &&
             ws_bytes >= ss2d_scan_bwd_sr_ws_bytes(p.batch, p.dim, p.L, p.G)) ? ws : nullptr;
     int rc;
-    if (dtype == SS2D_DTYPE_BF16) {
+    if (p.dtw) {   // fused delta: only the form SS2D issues (4-element rows, direction-aware, workspace), ranks 6 and 12
+        if (!p.ws || !vec4 || (p.R != 6 && p.R != 12)) return (int)hipErrorInvalidValue;
+        const bool h = dtype == SS2D_DTYPE_BF16;
+        if (p.R == 6) rc = h ? launch_sr<true, bf16, true, true, 6>(p, (int)nwg, s) : launch_sr<true, float, true, true, 6>(p, (int)nwg, s);
+        else rc = h ? launch_sr<true, bf16, true, true, 12>(p, (int)nwg, s) : launch_sr<true, float, true, true, 12>(p, (int)nwg, s);
+    } else if (dtype == SS2D_DTYPE_BF16) {
         if (dirs) rc = vec4 ? launch_sr_ws<true, bf16, true>(p, (int)nwg, s) : launch_sr_ws<false, bf16, true>(p, (int)nwg, s);
         else rc = vec4 ? launch_sr_ws<true, bf16, false>(p, (int)nwg, s) : launch_sr_ws<false, bf16, false>(p, (int)nwg, s);
     } else {

@@ -33,7 +33,10 @@ struct ScanFwdParams {
     int Gu;              // u has Gu groups per batch; scan group g reads u group g / (G / Gu)
     unsigned rev_mask;   // bit g: group g runs over its rows in reverse memory order
     long long bc_stride; // elements between consecutive (batch, group) blocks of B and of C (N*L when dense)
+    const float *dtw;    // DT kernels: dt_proj weight (G * dpg, R) in scan-group order; `delta` then points at the dts rows
+    int R;               // (R, L) of every (batch, group) block (same block stride as B / C), and delta is computed here
 };
+constexpr int MAXR = SS2D_MAX_DT_RANK;
 
 // Inclusive scan of (a, h) over the 16 lanes of each DPP row, two independent states interleaved so
 // that every DPP read is >= 2 instructions behind the write of its source (hardware hazard).
@@ -53,10 +56,15 @@ __device__ __forceinline__ void row_scan_pair(float &hx, float &hy, float &ax, f
 
 // FULL: dstate == 16 known at compile time (the only value Mamba-UNet uses): no per-pair bounds checks
 // DIRS: direction-aware build (rev_mask / u_groups honoured); false compiles the mirrored paths away
-template <int NW, bool HAS_Z, bool VEC4, bool FULL, typename IO, bool DIRS>
+// DT: delta is not read but computed in the kernel from the rank-R rows of the x_proj output (mamba_sys.py:417-420:
+//     delta[d, l] = sum_r dt_w[d, r] * dts[r, l]): the chunk's (R, 128) tile is staged in LDS beside B / C, the 16
+//     weight rows of the workgroup's channels once; 8R FMAs per lane and chunk instead of a (B, K*D, L) tensor.
+template <int NW, bool HAS_Z, bool VEC4, bool FULL, typename IO, bool DIRS, bool DT = false>
 __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p) {
     // [buffer][B|C][(pair*4 + quarter)*16 + seg] ; one f4 = (n,t),(n+1,t),(n,t+1),(n+1,t+1)
     __shared__ f4 tile[2][2][NP * 4 * 16];
+    __shared__ __align__(16) float dtile[DT ? 2 : 1][DT ? MAXR : 1][DT ? CHUNK : 4];
+    __shared__ float wtile[DT ? NW * 4 : 1][DT ? MAXR : 1];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, seg = lane & 15;
     int blk = xcd_remap(blockIdx.x, p.nwg);
@@ -89,11 +97,13 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     }
     const float Dc = p.D ? p.D[c] : 0.0f;
     const float bias = p.bias ? p.bias[c] : 0.0f;
+    const IO *__restrict__ dtsg = static_cast<const IO *>(p.delta) + (size_t)(b * p.G + g) * bcs;   // DT: the dts rows of this (b, g)
+    if (DT && seg < p.R) wtile[wave * 4 + row][seg] = p.dtw[(size_t)c * p.R + seg];                // visible behind the first barrier
 
     // software prefetch: the next chunk's u / delta are requested before the current chunk is computed
     float un[T], dn[T];
     load8d<VEC4, DIRS>(urow, seg * T, L, row_ok, rev, un);
-    load8d<VEC4, DIRS>(drow, seg * T, L, row_ok, rev, dn);
+    if (!DT) load8d<VEC4, DIRS>(drow, seg * T, L, row_ok, rev, dn);
 
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int buf = chunk & 1;
@@ -129,30 +139,51 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
                 tile[buf][m][(np * 4 + j0 + 1) * 16 + sg] = f4{lo.z, hi.z, lo.w, hi.w};
             }
         }
+        if (DT) {   // the (R, 128) tile of dts rows
+            for (int it = tid; it < p.R * 32; it += NW * 64) {
+                const int r = it >> 5, q4 = it & 31;
+                *reinterpret_cast<f4 *>(&dtile[buf][r][q4 * 4]) = load4m<VEC4>(dtsg + (size_t)r * L, base + q4 * 4, L, rev);
+            }
+        }
         // ---- this lane's 8 positions of u / delta
         const int p0 = base + seg * T;
         float uv[T], dt[T], du[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) { uv[t] = un[t]; dt[t] = dn[t]; }
+        for (int t = 0; t < T; ++t) { uv[t] = un[t]; dt[t] = DT ? 0.0f : dn[t]; }
         if (chunk + 1 < p.nchunks) {
             load8d<VEC4, DIRS>(urow, p0 + CHUNK, L, row_ok, rev, un);
-            load8d<VEC4, DIRS>(drow, p0 + CHUNK, L, row_ok, rev, dn);
+            if (!DT) load8d<VEC4, DIRS>(drow, p0 + CHUNK, L, row_ok, rev, dn);
         }
         float S = 0.0f;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            float x = dt[t] + bias, sg_unused;
-            if (p.softplus) x = softplus_sig<false>(x, sg_unused);
-            x = (row_ok && p0 + t < L) ? x : 0.0f;  // positions past L act as the identity (a = 1, b = 0)
-            dt[t] = x;
-            du[t] = x * uv[t];
-            S += x;
-        }
         f2 y2[T];
+        auto finish_dt = [&]() {
 #pragma unroll
-        for (int t = 0; t < T; ++t) y2[t] = f2{Dc * uv[t], 0.0f};
+            for (int t = 0; t < T; ++t) {
+                float x = dt[t] + bias, sg_unused;
+                if (p.softplus) x = softplus_sig<false>(x, sg_unused);
+                x = (row_ok && p0 + t < L) ? x : 0.0f;  // positions past L act as the identity (a = 1, b = 0)
+                dt[t] = x;
+                du[t] = x * uv[t];
+                S += x;
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) y2[t] = f2{Dc * uv[t], 0.0f};
+        };
+        if (!DT) finish_dt();
 
         __syncthreads();  // tile[buf] complete; the other buffer is free for the next chunk's staging
+
+        if (DT) {   // delta = dt_w[c, :] . dts[:, l] for this lane's 8 positions
+            const float *__restrict__ wr = wtile[wave * 4 + row];
+#pragma unroll 2
+            for (int r = 0; r < p.R; ++r) {
+                const float w = wr[r];
+                const f4 a = *reinterpret_cast<const f4 *>(&dtile[buf][r][seg * T]), b4 = *reinterpret_cast<const f4 *>(&dtile[buf][r][seg * T + 4]);
+                dt[0] = fmaf(w, a.x, dt[0]); dt[1] = fmaf(w, a.y, dt[1]); dt[2] = fmaf(w, a.z, dt[2]); dt[3] = fmaf(w, a.w, dt[3]);
+                dt[4] = fmaf(w, b4.x, dt[4]); dt[5] = fmaf(w, b4.y, dt[5]); dt[6] = fmaf(w, b4.z, dt[6]); dt[7] = fmaf(w, b4.w, dt[7]);
+            }
+            finish_dt();
+        }
 
         if (p.ckpt != nullptr && seg == 0 && row_ok) {  // state entering this chunk, for the backward
             float *ck = p.ckpt + (((size_t)b * p.dim + c) * p.nchunks + chunk) * N;
@@ -244,6 +275,16 @@ int launch_fwd(const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
     }
     return ss2d_take_launch_rc();
 }
+// the fused-delta form: 16 states, no z, 4-element rows, direction-aware addressing (the x_proj output is strided)
+template <typename IO>
+int launch_fwd_dt(int nw, const ScanFwdParams &p, hipStream_t s) {
+    dim3 grid(p.nwg);
+    if (nw == 4) ss2d_launch((scan_fwd_kernel<4, false, true, true, IO, true, true>), grid, dim3(256), 0, s, p);
+    else if (nw == 2) ss2d_launch((scan_fwd_kernel<2, false, true, true, IO, true, true>), grid, dim3(128), 0, s, p);
+    else ss2d_launch((scan_fwd_kernel<1, false, true, true, IO, true, true>), grid, dim3(64), 0, s, p);
+    return ss2d_take_launch_rc();
+}
+
 template <typename IO, bool DIRS>
 int launch_fwd_nw(int nw, const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
     return nw == 4 ? launch_fwd<4, IO, DIRS>(p, has_z, vec4, s) : nw == 2 ? launch_fwd<2, IO, DIRS>(p, has_z, vec4, s)
@@ -266,11 +307,38 @@ extern "C" int ss2d_selective_scan_fwd(int dtype, const void *u, const void *del
                                        dstate, ngroups, delta_softplus, ngroups, 0u, 0, stream);
 }
 
+static int scan_fwd_impl(int dtype, const void *u, const void *delta, const float *A, const void *B, const void *C, const float *D,
+                         const void *z, const float *delta_bias, void *out, float *last_state, float *ckpt, int batch, int dim, int L,
+                         int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask, long long bc_bg_stride,
+                         const float *dt_w, int dt_rank, void *stream);
+
 extern "C" int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void *delta, const float *A, const void *B,
                                            const void *C, const float *D, const void *z, const float *delta_bias,
                                            void *out, float *last_state, float *ckpt, int batch, int dim, int L,
                                            int dstate, int ngroups, int delta_softplus, int u_groups,
                                            unsigned rev_mask, long long bc_bg_stride, void *stream) {
+    return scan_fwd_impl(dtype, u, delta, A, B, C, D, z, delta_bias, out, last_state, ckpt, batch, dim, L, dstate, ngroups,
+                         delta_softplus, u_groups, rev_mask, bc_bg_stride, nullptr, 0, stream);
+}
+
+extern "C" int ss2d_selective_scan_core_fwd(int dtype, const void *u, const void *x_dbl, const float *dt_w, const float *A,
+                                            const float *D, const float *delta_bias, void *out, float *ckpt, int batch, int dim,
+                                            int L, int dstate, int ngroups, int dt_rank, int u_groups, unsigned rev_mask,
+                                            void *stream) {
+    if (!x_dbl || !dt_w) { ss2d_set_error("selective_scan_core_fwd: null required pointer"); return -2; }
+    if (dt_rank <= 0 || dt_rank > SS2D_MAX_DT_RANK) { ss2d_set_error("selective_scan_core_fwd: dt_rank %d not in [1, %d]", dt_rank, SS2D_MAX_DT_RANK); return -4; }
+    if (dstate != 16 || L % 4) { ss2d_set_error("selective_scan_core_fwd: needs dstate == 16 and L %% 4 == 0 (got %d, %d)", dstate, L); return -4; }
+    const size_t es = dtype == SS2D_DTYPE_BF16 ? 2 : 4;
+    const char *base = static_cast<const char *>(x_dbl);
+    const long long stride = (long long)(dt_rank + 2 * dstate) * L;
+    return scan_fwd_impl(dtype, u, x_dbl, A, base + (size_t)dt_rank * L * es, base + (size_t)(dt_rank + dstate) * L * es, D, nullptr,
+                         delta_bias, out, nullptr, ckpt, batch, dim, L, dstate, ngroups, 1, u_groups, rev_mask, stride, dt_w, dt_rank, stream);
+}
+
+static int scan_fwd_impl(int dtype, const void *u, const void *delta, const float *A, const void *B, const void *C, const float *D,
+                         const void *z, const float *delta_bias, void *out, float *last_state, float *ckpt, int batch, int dim, int L,
+                         int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask, long long bc_bg_stride,
+                         const float *dt_w, int dt_rank, void *stream) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_fwd: unknown dtype %d", dtype); return -1; }
     if (!u || !delta || !A || !B || !C || !out) { ss2d_set_error("selective_scan_fwd: null required pointer"); return -2; }
     if (batch <= 0 || dim <= 0 || L <= 0 || dstate <= 0 || ngroups <= 0) { ss2d_set_error("selective_scan_fwd: non-positive size"); return -3; }
@@ -283,6 +351,7 @@ extern "C" int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void 
     if (bc_bg_stride < bc_dense) { ss2d_set_error("selective_scan_fwd: bc_bg_stride %lld < dstate*L", bc_bg_stride); return -5; }
     ScanFwdParams p;
     p.Gu = u_groups; p.rev_mask = rev_mask; p.bc_stride = bc_bg_stride;
+    p.dtw = dt_w; p.R = dt_rank;
     p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
     p.D = D; p.z = z; p.bias = delta_bias; p.out = out; p.last = last_state; p.ckpt = ckpt;
     p.batch = batch; p.dim = dim; p.L = L; p.N = dstate; p.G = ngroups; p.dpg = dim / ngroups;
@@ -299,6 +368,12 @@ extern "C" int ss2d_selective_scan_dir_fwd(int dtype, const void *u, const void 
                       ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)out | (uintptr_t)z) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
     const bool dirs = rev_mask != 0 || u_groups != ngroups || bc_bg_stride != bc_dense;
+    if (dt_w) {
+        if (!vec4) { ss2d_set_error("selective_scan_core_fwd: u, x_dbl and out must be aligned to 4 elements"); return -7; }
+        const int rc = dtype == SS2D_DTYPE_BF16 ? launch_fwd_dt<bf16>(nw, p, s) : launch_fwd_dt<float>(nw, p, s);
+        if (rc) ss2d_set_error("selective_scan_core_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return rc;
+    }
     int rc = dtype == SS2D_DTYPE_BF16
                  ? (dirs ? launch_fwd_nw<bf16, true>(nw, p, z != nullptr, vec4, s) : launch_fwd_nw<bf16, false>(nw, p, z != nullptr, vec4, s))
                  : (dirs ? launch_fwd_nw<float, true>(nw, p, z != nullptr, vec4, s) : launch_fwd_nw<float, false>(nw, p, z != nullptr, vec4, s));

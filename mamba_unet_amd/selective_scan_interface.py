@@ -6,6 +6,8 @@ kernels of libss2d_hip.so through the C ABI of include/ss2d.h.  CPU tensors are 
 no fallback path."""
 from __future__ import annotations
 
+import os as _os
+
 import torch
 
 from . import _lib
@@ -243,6 +245,9 @@ class ScanCoreFn(torch.autograd.Function):
     (ss2d_xdbl_grad_pack) instead of two cast passes and a concatenation.  Arguments as `scan_merge_fn`, with
     dt_w (4, d, R) in place of delta."""
 
+    # class-wide switch (A/B runs; env SS2D_NO_FUSE_DELTA=1): compute delta inside the scan kernels for dt_rank 6 / 12
+    FUSE_DELTA = not _os.environ.get("SS2D_NO_FUSE_DELTA")
+
     @staticmethod
     def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None):
         if not x_dbl.is_cuda:
@@ -264,24 +269,34 @@ class ScanCoreFn(torch.autograd.Function):
         out = torch.empty((batch, dim, L), device=dev, dtype=io)
         ckpt = torch.empty((batch, dim, lib.ss2d_scan_num_chunks(L), N), device=dev, dtype=torch.float32) if needs_grad else None
         y = torch.empty((batch, H, W, Dch), device=dev, dtype=io)
+        fused_delta = ScanCoreFn.FUSE_DELTA and R in (6, 12) and L % 4 == 0 and N == 16
         with torch.cuda.device(dev):
-            if R in (6, 12) and L % 4 == 0:
+            if fused_delta:
+                # delta = dt_w . dts is computed inside the scan kernels (forward and backward): never materialised
+                delta = None
+                rc = lib.ss2d_selective_scan_core_fwd(code, _lib.ptr(u_), _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(A_), _lib.ptr(D_),
+                                                      _lib.ptr(bias_), _lib.ptr(out), _lib.ptr(ckpt), batch, dim, L, N, 4, R,
+                                                      ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, _stream())
+                _lib.check(rc, "ss2d_selective_scan_core_fwd")
+            elif R in (6, 12) and L % 4 == 0:
                 delta = torch.empty((batch, dim, L), device=dev, dtype=io)
                 rc = lib.ss2d_dt_proj_fwd(code, _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(delta), batch, 4, Dch, R, L, Cx * L, _stream())
                 _lib.check(rc, "ss2d_dt_proj_fwd")
             else:   # other ranks: library GEMM
                 with torch.autocast("cuda", enabled=False):
                     delta = torch.matmul(w32.to(io).unsqueeze(0), xd[:, :, :R]).reshape(batch, dim, L)
-            if (Cx * L) % 4 == 0:
-                B_, C_, bcs = xd[:, :, R:R + N], xd[:, :, R + N:], Cx * L
-            else:
-                B_, C_, bcs = xd[:, :, R:R + N].contiguous(), xd[:, :, R + N:].contiguous(), N * L
-            rc = lib.ss2d_selective_scan_dir_fwd(code, _lib.ptr(u_), _lib.ptr(delta), _lib.ptr(A_), _lib.ptr(B_), _lib.ptr(C_),
-                                                 _lib.ptr(D_), None, _lib.ptr(bias_), _lib.ptr(out), None, _lib.ptr(ckpt),
-                                                 batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, bcs, _stream())
-            _lib.check(rc, "ss2d_selective_scan_dir_fwd")
+            if not fused_delta:
+                if (Cx * L) % 4 == 0:
+                    B_, C_, bcs = xd[:, :, R:R + N], xd[:, :, R + N:], Cx * L
+                else:
+                    B_, C_, bcs = xd[:, :, R:R + N].contiguous(), xd[:, :, R + N:].contiguous(), N * L
+                rc = lib.ss2d_selective_scan_dir_fwd(code, _lib.ptr(u_), _lib.ptr(delta), _lib.ptr(A_), _lib.ptr(B_), _lib.ptr(C_),
+                                                     _lib.ptr(D_), None, _lib.ptr(bias_), _lib.ptr(out), None, _lib.ptr(ckpt),
+                                                     batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, bcs, _stream())
+                _lib.check(rc, "ss2d_selective_scan_dir_fwd")
             rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(out), _lib.ptr(y), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_gather")
+        ctx.fused_delta = fused_delta
         ctx.save_for_backward(u_, delta, A_, xd, w32, D_, bias_, ckpt)
         ctx.meta = (code, H, W, R, u2.dtype, x_dbl.dtype, dt_w.dtype, A.dtype, None if D is None else D.dtype,
                     None if delta_bias is None else delta_bias.dtype, None if x is None else x.dtype)
@@ -291,18 +306,22 @@ class ScanCoreFn(torch.autograd.Function):
     def backward(ctx, dy):
         u, delta, A, xd, w32, D, bias, ckpt = ctx.saved_tensors
         code, H, W, R, u_dt, xdbl_dt, w_dt, A_dt, D_dt, b_dt, x_dt = ctx.meta
-        batch, dim, L = delta.shape
+        batch, L = xd.shape[0], xd.shape[3]
+        dim = A.shape[0]
         N, Dch, Cx = A.shape[1], dim // 4, xd.shape[2]
         io = xd.dtype
         lib = _lib.load()
         g = dy.to(io).contiguous()
         dev = g.device
         dys2 = torch.empty((batch, 2, Dch, L), device=dev, dtype=io)
-        du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
+        du = torch.empty((batch, dim, L), device=dev, dtype=io)
+        ddelta = torch.empty_like(du)
         sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
         dA, dD, dbias, dB, dC, ws, wsb = _bwd_buffers(lib, dev, batch, dim, L, N, 4, False, sh(A), sh(D), sh(bias),
                                                        (batch, 4, N, L), (batch, 4, N, L))
-        if (Cx * L) % 4 == 0:
+        if ctx.fused_delta:
+            B_ = C_ = None
+        elif (Cx * L) % 4 == 0:
             B_, C_, bcs = xd[:, :, R:R + N], xd[:, :, R + N:], Cx * L
         else:
             B_, C_, bcs = xd[:, :, R:R + N].contiguous(), xd[:, :, R + N:].contiguous(), N * L
@@ -310,12 +329,19 @@ class ScanCoreFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_scatter")
-            rc = lib.ss2d_selective_scan_dir_bwd_ws(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B_), _lib.ptr(C_),
-                                                    _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
-                                                    _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
-                                                    _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
-                                                    ScanMergeFn.REV_MASK, bcs, _lib.ptr(ws), wsb, _stream())
-            _lib.check(rc, "ss2d_selective_scan_dir_bwd_ws")
+            if ctx.fused_delta:
+                rc = lib.ss2d_selective_scan_core_bwd(code, _lib.ptr(u), _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(A), _lib.ptr(D),
+                                                      _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du), _lib.ptr(ddelta),
+                                                      _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), _lib.ptr(dbias), batch, dim,
+                                                      L, N, 4, R, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, _lib.ptr(ws), wsb, _stream())
+                _lib.check(rc, "ss2d_selective_scan_core_bwd")
+            else:
+                rc = lib.ss2d_selective_scan_dir_bwd_ws(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B_), _lib.ptr(C_),
+                                                        _lib.ptr(D), None, _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du),
+                                                        _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), None,
+                                                        _lib.ptr(dbias), batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS,
+                                                        ScanMergeFn.REV_MASK, bcs, _lib.ptr(ws), wsb, _stream())
+                _lib.check(rc, "ss2d_selective_scan_dir_bwd_ws")
             dx = du2 = None
             if x_dt is not None:      # all four directions' du -> dx in one pass (the adjoint of the scatter)
                 dx = torch.empty((batch, Dch, H, W), device=dev, dtype=io)
