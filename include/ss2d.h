@@ -266,6 +266,13 @@ int ss2d_ln_head_bwd(int in_dtype, int out_dtype, const void *dlogits, const voi
  * _bwd: dlogits (same layout and dtype as logits, WRITTEN) from gstats = dL/dstats (3C+1, device):
  * dlogit_c = p_c*(q_c - sum_k p_k q_k) + gstats[3C]*(p_c - [y==c]),  q_c = gstats[c]*[y==c] + 2*gstats[2C+c]*p_c.
  * A label outside [0, C) contributes to no statistic (and gets no cross-entropy gradient).  C <= 16. */
+/* Weight gradients of x_proj (mamba_sys.py:407) and dt_proj (:420), whose operands are channel-major (rows = channels,
+ * positions contiguous):  out[g*sog + i*soi + j*soj] += sum_b sum_l P[b*spb + g*spg + i*L + l] * Q[b*sqb + g*sqg + j*L + l]
+ * for i < Mb (the wide operand), j < Ns; P, Q in dtype, out fp32 ACCUMULATED INTO (caller zero-fills; float atomics).
+ * L, the strides and the base addresses must be multiples of 4 elements.  MFMA (bf16: exact products, fp32 sums). */
+int ss2d_chan_wgrad(int dtype, const void *P, const void *Q, float *out, int B, int G, int Mb, int Ns, int L, long long spb,
+                    long long spg, long long sqb, long long sqg, long long sog, long long soi, long long soj, void *stream);
+
 /* Column sums out[j] = sum_r x[r*ldx + j] (fp32) of a (rows, M) matrix in dtype: autograd's bias gradient of the Linears
  * that have a bias (`concat_back_dim`, mamba_sys.py:774-778, applied :835).  Deterministic (per-workgroup partial rows in
  * `workspace`, ss2d_colsum_workspace_floats(M) floats, added in a fixed order); out is WRITTEN. */

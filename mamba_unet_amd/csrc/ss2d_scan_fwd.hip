@@ -56,6 +56,16 @@ __device__ __forceinline__ void row_scan_pair(float &hx, float &hy, float &ax, f
 
 // FULL: dstate == 16 known at compile time (the only value Mamba-UNet uses): no per-pair bounds checks
 // DIRS: direction-aware build (rev_mask / u_groups honoured); false compiles the mirrored paths away
+#ifdef SS2D_FWD_PROBE
+// timing probes (debug builds only: make variant SRC=ss2d_scan_fwd DEFS=-DSS2D_FWD_PROBE, tools/probe_fwd.py)
+__device__ unsigned long long *g_fwd_probe;
+#define FWD_NPROBE 8
+#define FWD_PROBE(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                          pacc[i] += (unsigned)(t_ - tprev); tprev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define FWD_PROBE(i) do { } while (0)
+#endif
+
 // DT: delta is not read but computed in the kernel from the rank-R rows of the x_proj output (mamba_sys.py:417-420:
 //     delta[d, l] = sum_r dt_w[d, r] * dts[r, l]): the chunk's (R, 128) tile is staged in LDS beside B / C, the 16
 //     weight rows of the workgroup's channels once; 8R FMAs per lane and chunk instead of a (B, K*D, L) tensor.
@@ -65,6 +75,11 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     __shared__ f4 tile[2][2][NP * 4 * 16];
     __shared__ __align__(16) float dtile[DT ? 2 : 1][DT ? MAXR : 1][DT ? CHUNK : 4];
     __shared__ float wtile[DT ? NW * 4 : 1][DT ? MAXR : 1];
+#ifdef SS2D_FWD_PROBE
+    unsigned pacc[FWD_NPROBE] = {};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    const unsigned long long tstart = tprev;
+#endif
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, seg = lane & 15;
     int blk = xcd_remap(blockIdx.x, p.nwg);
@@ -105,40 +120,58 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     load8d<VEC4, DIRS>(urow, seg * T, L, row_ok, rev, un);
     if (!DT) load8d<VEC4, DIRS>(drow, seg * T, L, row_ok, rev, dn);
 
+    // B/C tile item `it` = (state pair, 4 positions): two rows of each matrix
+    auto tile_fetch = [&](int base_, int it, f4 (&lo)[2], f4 (&hi)[2]) {
+        const int np = it >> 5, q4 = it & 31;
+        const int pos = base_ + q4 * 4;
+        const int n0 = 2 * np, n1 = 2 * np + 1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const IO *__restrict__ M = m ? Cg : Bg;
+            lo[m] = f4{0, 0, 0, 0};
+            hi[m] = f4{0, 0, 0, 0};
+            if (DIRS) {
+                if (n0 < N) lo[m] = load4m<VEC4>(M + (size_t)n0 * L, pos, L, rev);
+                if (n1 < N) hi[m] = load4m<VEC4>(M + (size_t)n1 * L, pos, L, rev);
+            } else if (VEC4) {
+                if (pos < L) {
+                    if (n0 < N) lo[m] = ld4(M + (size_t)n0 * L + pos);
+                    if (n1 < N) hi[m] = ld4(M + (size_t)n1 * L + pos);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (pos + e < L) {
+                        if (n0 < N) lo[m][e] = ld1(M + (size_t)n0 * L + pos + e);
+                        if (n1 < N) hi[m][e] = ld1(M + (size_t)n1 * L + pos + e);
+                    }
+                }
+            }
+        }
+    };
+    auto tile_put = [&](int buf_, int it, const f4 (&lo)[2], const f4 (&hi)[2]) {
+        const int np = it >> 5, q4 = it & 31, j0 = (q4 & 1) * 2, sg = q4 >> 1;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            tile[buf_][m][(np * 4 + j0) * 16 + sg] = f4{lo[m].x, hi[m].x, lo[m].y, hi[m].y};
+            tile[buf_][m][(np * 4 + j0 + 1) * 16 + sg] = f4{lo[m].z, hi[m].z, lo[m].w, hi[m].w};
+        }
+    };
+    // (Requesting the next chunk's item a chunk ahead -- the probes show 16 % of a wave's time in this round trip -- was
+    // measured slower: 16 more registers cost the third wave per SIMD (386 us) or spills (345 us) against 330 us; the
+    // other waves of the SIMD already cover the wait.)
+
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int buf = chunk & 1;
         const int base = chunk * CHUNK;
+        FWD_PROBE(0);
         // ---- stage the chunk's B/C tile (shared by all waves of the workgroup)
         for (int it = tid; it < NP * 32; it += NW * 64) {
-            const int np = it >> 5, q4 = it & 31;
-            const int pos = base + q4 * 4;
-            const int n0 = 2 * np, n1 = 2 * np + 1;
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const IO *__restrict__ M = m ? Cg : Bg;
-                f4 lo = f4{0, 0, 0, 0}, hi = f4{0, 0, 0, 0};
-                if (DIRS) {
-                    if (n0 < N) lo = load4m<VEC4>(M + (size_t)n0 * L, pos, L, rev);
-                    if (n1 < N) hi = load4m<VEC4>(M + (size_t)n1 * L, pos, L, rev);
-                } else if (VEC4) {
-                    if (pos < L) {
-                        if (n0 < N) lo = ld4(M + (size_t)n0 * L + pos);
-                        if (n1 < N) hi = ld4(M + (size_t)n1 * L + pos);
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (pos + e < L) {
-                            if (n0 < N) lo[e] = ld1(M + (size_t)n0 * L + pos + e);
-                            if (n1 < N) hi[e] = ld1(M + (size_t)n1 * L + pos + e);
-                        }
-                    }
-                }
-                const int j0 = (q4 & 1) * 2, sg = q4 >> 1;
-                tile[buf][m][(np * 4 + j0) * 16 + sg] = f4{lo.x, hi.x, lo.y, hi.y};
-                tile[buf][m][(np * 4 + j0 + 1) * 16 + sg] = f4{lo.z, hi.z, lo.w, hi.w};
-            }
+            f4 lo[2], hi[2];
+            tile_fetch(base, it, lo, hi);
+            tile_put(buf, it, lo, hi);
         }
+        FWD_PROBE(1);
         if (DT) {   // the (R, 128) tile of dts rows
             for (int it = tid; it < p.R * 32; it += NW * 64) {
                 const int r = it >> 5, q4 = it & 31;
@@ -170,8 +203,10 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
             for (int t = 0; t < T; ++t) y2[t] = f2{Dc * uv[t], 0.0f};
         };
         if (!DT) finish_dt();
+        FWD_PROBE(2);
 
         __syncthreads();  // tile[buf] complete; the other buffer is free for the next chunk's staging
+        FWD_PROBE(3);
 
         if (DT) {   // delta = dt_w[c, :] . dts[:, l] for this lane's 8 positions
             const float *__restrict__ wr = wtile[wave * 4 + row];
@@ -199,6 +234,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
                 }
             }
         }
+        FWD_PROBE(4);
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             if (FULL || 2 * np < N) {  // wave-uniform
@@ -240,6 +276,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        FWD_PROBE(5);
         float yv[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) yv[t] = y2[t].x + y2[t].y;
@@ -250,7 +287,15 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
             for (int t = 0; t < T; ++t) yv[t] *= zv[t] * sigmoidf_fast(zv[t]);
         }
         store8d<VEC4, DIRS>(orow, p0, L, row_ok, rev, yv);
+        FWD_PROBE(6);
     }
+#ifdef SS2D_FWD_PROBE
+    if (g_fwd_probe && lane == 0) {
+        unsigned long long *q = g_fwd_probe + ((size_t)blockIdx.x * NW + wave) * (FWD_NPROBE + 1);
+        for (int i = 0; i < FWD_NPROBE; ++i) q[i] = pacc[i];
+        q[FWD_NPROBE] = __builtin_amdgcn_s_memtime() - tstart;
+    }
+#endif
     if (p.last != nullptr && seg == 0 && row_ok) {
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
@@ -292,6 +337,10 @@ int launch_fwd_nw(int nw, const ScanFwdParams &p, bool has_z, bool vec4, hipStre
 }
 
 }  // namespace
+
+#ifdef SS2D_FWD_PROBE
+extern "C" int ss2d_debug_set_fwd_probe(void *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_probe), &buf, sizeof(buf)); }
+#endif
 
 extern "C" int ss2d_scan_num_chunks(int L) { return (L + CHUNK - 1) / CHUNK; }
 

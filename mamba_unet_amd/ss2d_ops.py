@@ -167,6 +167,29 @@ def linear_wgrad(grad_out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
     return dw
 
 
+def chan_wgrad(P: torch.Tensor, Q: torch.Tensor) -> torch.Tensor:
+    """out (G, M, N) fp32 = sum_b P[b, g] @ Q[b, g]^T for channel-major operands P (B, G, M, L), Q (B, G, N, L) whose rows
+    are contiguous and L apart (views into wider blocks are fine): the weight gradient of dt_proj (mamba_sys.py:420; also
+    right for x_proj's, :407, where the library's batched GEMM is as fast) on the MFMA kernel of csrc/ss2d_cmwgrad.hip.
+    None when the layout does not qualify."""
+    _need_gpu(P, "chan_wgrad")
+    B, G, M, L = P.shape
+    N = Q.shape[2]
+    if (Q.shape[0], Q.shape[1], Q.shape[3]) != (B, G, L) or P.dtype != Q.dtype or P.dtype not in (torch.float32, torch.bfloat16):
+        return None
+    ok = lambda t: t.stride(3) == 1 and t.stride(2) == L and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0  # noqa: E731
+    if L % 4 or not ok(P) or not ok(Q) or (P.data_ptr() | Q.data_ptr()) % (4 * P.element_size()):
+        return None
+    code = _BF16 if P.dtype == torch.bfloat16 else _F32
+    out = torch.zeros((G, M, N), device=P.device, dtype=torch.float32)
+    wide, narrow, soi, soj, Mb, Ns = (P, Q, N, 1, M, N) if M >= N else (Q, P, 1, N, N, M)
+    with torch.cuda.device(P.device):
+        rc = _lib.load().ss2d_chan_wgrad(code, _lib.ptr(wide), _lib.ptr(narrow), _lib.ptr(out), B, G, Mb, Ns, L, wide.stride(0),
+                                         wide.stride(1), narrow.stride(0), narrow.stride(1), M * N, soi, soj, _stream())
+    _lib.check(rc, "ss2d_chan_wgrad")
+    return out
+
+
 def colsum(g: torch.Tensor) -> torch.Tensor:
     """fp32 sum over all leading axes of g[..., M] (a Linear's bias gradient), csrc/ss2d_colsum.hip: deterministic, and
     unlike torch's multi-block reduction it replays correctly inside a captured HIP graph."""

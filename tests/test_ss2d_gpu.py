@@ -454,3 +454,22 @@ def test_concat_linear_matches_cat_then_linear(B, H, W, C, dtype):
     assert rel_l2(y.detach().float().cpu(), yr.detach()) < tol
     assert rel_l2(xd.grad.float().cpu(), xr.grad) < tol and rel_l2(sd.grad.float().cpu(), sr.grad) < tol
     assert rel_l2(lin.weight.grad.cpu(), ref.weight.grad) < tol and rel_l2(lin.bias.grad.cpu(), ref.bias.grad) < tol
+
+
+@pytest.mark.parametrize("B,G,M,N,L,dtype", [(3, 4, 192, 6, 3136, torch.float32), (2, 2, 76, 192, 784, torch.float32),
+                                             (24, 4, 192, 6, 3136, torch.bfloat16), (24, 2, 76, 192, 3136, torch.bfloat16),
+                                             (5, 4, 768, 24, 196, torch.bfloat16), (4, 2, 112, 768, 196, torch.float32),
+                                             (2, 1, 33, 100, 20, torch.float32), (3, 2, 160, 1536, 64, torch.bfloat16)])
+def test_chan_wgrad_mfma(B, G, M, N, L, dtype):
+    """out[g] = sum_b P[b, g] Q[b, g]^T for channel-major operands (the dt_proj / x_proj weight gradients), operands taken
+    as row ranges of wider blocks like the dts rows of x_dbl, against an fp64 einsum of the same stored values."""
+    from mamba_unet_amd.ss2d_ops import chan_wgrad
+    gen = torch.Generator().manual_seed(M + N + L)
+    Pw = torch.randn(B, G, M + 8, L, generator=gen).to(dtype)
+    Qw = torch.randn(B, G, N + 4, L, generator=gen).to(dtype)
+    Pd, Qd = Pw.cuda()[:, :, 8:], Qw.cuda()[:, :, :N]
+    got = chan_wgrad(Pd, Qd)
+    assert got is not None and got.shape == (G, M, N) and got.dtype == torch.float32
+    want = torch.einsum("bgml,bgnl->gmn", Pw[:, :, 8:].double(), Qw[:, :, :N].double())
+    assert rel_l2(got.cpu(), want) < 1e-5
+    assert chan_wgrad(Pd[..., :L - 1], Qd[..., :L - 1]) is None        # rows no longer L apart: the caller falls back
