@@ -22,15 +22,15 @@ __device__ __forceinline__ f2 splat2(float x) { return f2{x, x}; }
 __device__ __forceinline__ f2 exp2_2(f2 x) { return f2{hw_exp2(x.x), hw_exp2(x.y)}; }
 
 // softplus(x) with torch's threshold 20; also returns sigmoid(x) (= d softplus / dx) when asked.
-// log1p(e) is evaluated as log(w) * e / (w - 1), w = 1 + e, which keeps full relative accuracy for the
-// small e (delta ~ 1e-3) this model lives on.
+// log1p(e) is evaluated as log(w) + (e - (w - 1)), w = 1 + e: w - 1 is exact, so e - (w - 1) is the part of e that
+// rounding 1 + e dropped, and d log(w) / dw = 1 / w is 1 to within e where that part matters (e << 1) and the part is
+// below half an ulp of w where it is not.  Full relative accuracy for the small e (delta ~ 1e-3) this model lives on,
+// two transcendentals and no division (the form log(w) * e / (w - 1) costs a v_rcp_f32 and a select more).
 template <bool WANT_SIG>
 __device__ __forceinline__ float softplus_sig(float x, float &sig) {
     const float e = hw_exp2(x * SS2D_LOG2E);
     const float w = 1.0f + e;
-    const float d = w - 1.0f;
-    const float lg = hw_log2(w) * SS2D_LN2;
-    float r = (d == 0.0f) ? e : lg * (e * hw_rcp(d));
+    const float r = fmaf(hw_log2(w), SS2D_LN2, e - (w - 1.0f));
     if (WANT_SIG) sig = (x > 20.0f) ? 1.0f : e * hw_rcp(w);
     return (x > 20.0f) ? x : r;
 }

@@ -8,7 +8,7 @@
 //   * 4-step Hillis-Steele scan of the (decay, state) pairs across the 16 lanes of a row with DPP
 //     row_shr modifiers folded into v_fmac/v_mul (no LDS, no cross-row traffic);
 //   * second local pass from the lane's true incoming state, fused with y += C*h;
-//   * the state leaving a chunk is rotated to lane 0 of the row (row_ror:1) for the next chunk.
+//   * the state leaving a chunk is moved to lane 0 of the row (row_shl:15, zero elsewhere) for the next chunk.
 // B and C of the (batch, group) are shared by every channel of the group: the workgroup stages the
 // chunk's B/C tile once in LDS, interleaving state pairs so one ds_read_b128 feeds two packed FMAs.
 // The product of exp(delta*A) over a lane's items is exp(A * sum(delta)), so the lane aggregate costs
@@ -75,6 +75,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     __shared__ f4 tile[2][2][NP * 4 * 16];
     __shared__ __align__(16) float dtile[DT ? 2 : 1][DT ? MAXR : 1][DT ? CHUNK : 4];
     __shared__ float wtile[DT ? NW * 4 : 1][DT ? MAXR : 1];
+    __shared__ f2 A2s[NW * 4][NP];
 #ifdef SS2D_FWD_PROBE
     unsigned pacc[FWD_NPROBE] = {};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
@@ -102,23 +103,38 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * bcs;
     const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * bcs;
 
-    f2 A2[NP], carry[NP];
-#pragma unroll
-    for (int np = 0; np < NP; ++np) {
-        const float a0 = (2 * np < N) ? p.A[(size_t)c * N + 2 * np] : 0.0f;
-        const float a1 = (2 * np + 1 < N) ? p.A[(size_t)c * N + 2 * np + 1] : 0.0f;
-        A2[np] = f2{a0, a1} * SS2D_LOG2E;
-        carry[np] = f2{0.0f, 0.0f};
+    // A * log2(e) of the row's 16 states lives in LDS (one ds_read_b64 per pair and chunk): 16 registers that pay for the
+    // B/C tile prefetch below without giving up the third wave per SIMD
+    f2 carry[NP];
+    if (seg < NP) {
+        const float a0 = (2 * seg < N) ? p.A[(size_t)c * N + 2 * seg] : 0.0f;
+        const float a1 = (2 * seg + 1 < N) ? p.A[(size_t)c * N + 2 * seg + 1] : 0.0f;
+        A2s[wave * 4 + row][seg] = f2{a0, a1} * SS2D_LOG2E;           // visible behind the first barrier
     }
+#pragma unroll
+    for (int np = 0; np < NP; ++np) carry[np] = f2{0.0f, 0.0f};
     const float Dc = p.D ? p.D[c] : 0.0f;
     const float bias = p.bias ? p.bias[c] : 0.0f;
     const IO *__restrict__ dtsg = static_cast<const IO *>(p.delta) + (size_t)(b * p.G + g) * bcs;   // DT: the dts rows of this (b, g)
     if (DT && seg < p.R) wtile[wave * 4 + row][seg] = p.dtw[(size_t)c * p.R + seg];                // visible behind the first barrier
 
-    // software prefetch: the next chunk's u / delta are requested before the current chunk is computed
-    float un[T], dn[T];
-    load8d<VEC4, DIRS>(urow, seg * T, L, row_ok, rev, un);
-    if (!DT) load8d<VEC4, DIRS>(drow, seg * T, L, row_ok, rev, dn);
+    // software prefetch: the next chunk's u / delta are requested as soon as the current chunk's are consumed, into the
+    // same registers.  VEC4: the address is clamped into the row instead of the load being guarded (a guarded load is
+    // sunk into its branch with a full wait); what a clamped load returns past L is real data of the same row and is
+    // switched off by dt = 0 below.
+    float uv[T], dn[T];
+    auto fetch_row = [&](const IO *__restrict__ rowp, int q0, float (&v)[T]) {
+        if (VEC4) {
+            const int pa = q0 < L - 4 ? q0 : L - 4, pb = q0 + 4 < L - 4 ? q0 + 4 : L - 4;
+            f4 a = ld4(rowp + (unsigned)(rev ? L - 4 - pa : pa)), b = ld4(rowp + (unsigned)(rev ? L - 4 - pb : pb));
+            if (rev) { a = f4{a.w, a.z, a.y, a.x}; b = f4{b.w, b.z, b.y, b.x}; }
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+            load8d<VEC4, DIRS>(rowp, q0, L, row_ok, rev, v);
+        }
+    };
+    fetch_row(urow, seg * T, uv);
+    if (!DT) fetch_row(drow, seg * T, dn);
 
     // B/C tile item `it` = (state pair, 4 positions): two rows of each matrix
     auto tile_fetch = [&](int base_, int it, f4 (&lo)[2], f4 (&hi)[2]) {
@@ -130,7 +146,13 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
             const IO *__restrict__ M = m ? Cg : Bg;
             lo[m] = f4{0, 0, 0, 0};
             hi[m] = f4{0, 0, 0, 0};
-            if (DIRS) {
+            if (VEC4 && FULL) {   // clamped, unguarded (positions past L meet du = 0 and are never stored)
+                const int pc = pos < L - 4 ? pos : L - 4;
+                const unsigned off = (unsigned)(rev ? L - 4 - pc : pc);
+                lo[m] = ld4(M + (size_t)n0 * L + off);
+                hi[m] = ld4(M + (size_t)n1 * L + off);
+                if (rev) { lo[m] = f4{lo[m].w, lo[m].z, lo[m].y, lo[m].x}; hi[m] = f4{hi[m].w, hi[m].z, hi[m].y, hi[m].x}; }
+            } else if (DIRS) {
                 if (n0 < N) lo[m] = load4m<VEC4>(M + (size_t)n0 * L, pos, L, rev);
                 if (n1 < N) hi[m] = load4m<VEC4>(M + (size_t)n1 * L, pos, L, rev);
             } else if (VEC4) {
@@ -150,26 +172,35 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
         }
     };
     auto tile_put = [&](int buf_, int it, const f4 (&lo)[2], const f4 (&hi)[2]) {
-        const int np = it >> 5, q4 = it & 31, j0 = (q4 & 1) * 2, sg = q4 >> 1;
+        // slot of (pair, quarter j, segment): segments of quarters 2, 3 are stored 8 places on (sg ^ 8), so that the
+        // sixteen lanes that write one ds_write_b128 phase -- eight segments x the two quarter pairs -- hit sixteen
+        // different 16-byte bank groups (unswizzled, lanes 2k and 2k+1 collide: 10 % of the LDS cycles)
+        const int np = it >> 5, q4 = it & 31, j0 = (q4 & 1) * 2, sg = (q4 >> 1) ^ (j0 * 4);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             tile[buf_][m][(np * 4 + j0) * 16 + sg] = f4{lo[m].x, hi[m].x, lo[m].y, hi[m].y};
             tile[buf_][m][(np * 4 + j0 + 1) * 16 + sg] = f4{lo[m].z, hi[m].z, lo[m].w, hi[m].w};
         }
     };
-    // (Requesting the next chunk's item a chunk ahead -- the probes show 16 % of a wave's time in this round trip -- was
-    // measured slower: 16 more registers cost the third wave per SIMD (386 us) or spills (345 us) against 330 us; the
-    // other waves of the SIMD already cover the wait.)
+    // NW == 4: a thread stages exactly one tile item per chunk and requests it a chunk ahead (the probes put 18 % of a
+    // wave's time into this round trip when it is taken at the top of the chunk)
+    constexpr bool TPRE = NW == 4 && VEC4 && FULL;
+    f4 tlo[2], thi[2];
+    if (TPRE) tile_fetch(0, tid, tlo, thi);
 
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int buf = chunk & 1;
         const int base = chunk * CHUNK;
         FWD_PROBE(0);
         // ---- stage the chunk's B/C tile (shared by all waves of the workgroup)
-        for (int it = tid; it < NP * 32; it += NW * 64) {
-            f4 lo[2], hi[2];
-            tile_fetch(base, it, lo, hi);
-            tile_put(buf, it, lo, hi);
+        if (TPRE) {
+            tile_put(buf, tid, tlo, thi);
+        } else {
+            for (int it = tid; it < NP * 32; it += NW * 64) {
+                f4 lo[2], hi[2];
+                tile_fetch(base, it, lo, hi);
+                tile_put(buf, it, lo, hi);
+            }
         }
         FWD_PROBE(1);
         if (DT) {   // the (R, 128) tile of dts rows
@@ -180,33 +211,39 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
         }
         // ---- this lane's 8 positions of u / delta
         const int p0 = base + seg * T;
-        float uv[T], dt[T], du[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) { uv[t] = un[t]; dt[t] = DT ? 0.0f : dn[t]; }
-        if (chunk + 1 < p.nchunks) {
-            load8d<VEC4, DIRS>(urow, p0 + CHUNK, L, row_ok, rev, un);
-            if (!DT) load8d<VEC4, DIRS>(drow, p0 + CHUNK, L, row_ok, rev, dn);
-        }
+        float dt[T], du[T];
         float S = 0.0f;
         f2 y2[T];
+        // valid positions of this lane in this chunk (0 for a padding row): positions past L act as the identity (a = 1, b = 0)
+        const int nv = row_ok ? L - p0 : 0;
         auto finish_dt = [&]() {
 #pragma unroll
             for (int t = 0; t < T; ++t) {
-                float x = dt[t] + bias, sg_unused;
+                float x = (DT ? dt[t] : dn[t]) + bias, sg_unused;
                 if (p.softplus) x = softplus_sig<false>(x, sg_unused);
-                x = (row_ok && p0 + t < L) ? x : 0.0f;  // positions past L act as the identity (a = 1, b = 0)
+                x = t < nv ? x : 0.0f;
                 dt[t] = x;
                 du[t] = x * uv[t];
                 S += x;
             }
+            // D*u enters through both halves of the packed accumulator (exact halving; saves zeroing the second half)
 #pragma unroll
-            for (int t = 0; t < T; ++t) y2[t] = f2{Dc * uv[t], 0.0f};
+            for (int t = 0; t < T; ++t) y2[t] = splat2(uv[t]) * f2{0.5f * Dc, 0.5f * Dc};
+            // u / delta of the next chunk, into the registers just consumed (unconditional: behind the last chunk the
+            // clamped address re-reads the row's tail, and a conditional load would bring back a register copy per value)
+            fetch_row(urow, p0 + CHUNK, uv);
+            if (!DT) fetch_row(drow, p0 + CHUNK, dn);
         };
+        if (DT) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) dt[t] = 0.0f;
+        }
         if (!DT) finish_dt();
         FWD_PROBE(2);
 
         __syncthreads();  // tile[buf] complete; the other buffer is free for the next chunk's staging
         FWD_PROBE(3);
+        if (TPRE) tile_fetch(base + CHUNK, tid, tlo, thi);      // unconditional, clamped (see fetch_row)
 
         if (DT) {   // delta = dt_w[c, :] . dts[:, l] for this lane's 8 positions
             const float *__restrict__ wr = wtile[wave * 4 + row];
@@ -239,19 +276,20 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
         for (int np = 0; np < NP; ++np) {
             if (FULL || 2 * np < N) {  // wave-uniform
                 f2 a[T], bb[T];
+                const f2 A2np = A2s[wave * 4 + row][np];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f4 Bq = tile[buf][0][(np * 4 + j) * 16 + seg];
+                    const f4 Bq = tile[buf][0][(np * 4 + j) * 16 + (seg ^ ((j >> 1) * 8))];
                     bb[2 * j] = splat2(du[2 * j]) * f2{Bq.x, Bq.y};
                     bb[2 * j + 1] = splat2(du[2 * j + 1]) * f2{Bq.z, Bq.w};
                 }
 #pragma unroll
-                for (int t = 0; t < T; ++t) a[t] = exp2_2(splat2(dt[t]) * A2[np]);
+                for (int t = 0; t < T; ++t) a[t] = exp2_2(splat2(dt[t]) * A2np);
                 // pass 1: lane-local recurrence (lane 0 of the row starts from the carried state)
-                f2 h = f2{seg == 0 ? carry[np].x : 0.0f, seg == 0 ? carry[np].y : 0.0f};
+                f2 h = carry[np];                                  // zero outside lane 0 of the row (see below)
 #pragma unroll
                 for (int t = 0; t < T; ++t) h = fma2(a[t], h, bb[t]);
-                f2 at = exp2_2(splat2(S) * A2[np]);
+                f2 at = exp2_2(splat2(S) * A2np);
                 float hx = h.x, hy = h.y, ax = at.x, ay = at.y;
                 row_scan_pair(hx, hy, ax, ay);
                 // state entering this lane = inclusive result of the lane to the left (carry for lane 0)
@@ -260,14 +298,16 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
                 // pass 2: true states, fused with the C contraction
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f4 Cq = tile[buf][1][(np * 4 + j) * 16 + seg];
+                    const f4 Cq = tile[buf][1][(np * 4 + j) * 16 + (seg ^ ((j >> 1) * 8))];
                     h = fma2(a[2 * j], h, bb[2 * j]);
                     y2[2 * j] = fma2(f2{Cq.x, Cq.y}, h, y2[2 * j]);
                     h = fma2(a[2 * j + 1], h, bb[2 * j + 1]);
                     y2[2 * j + 1] = fma2(f2{Cq.z, Cq.w}, h, y2[2 * j + 1]);
                 }
-                carry[np].x = dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, h.x);
-                carry[np].y = dpp_mov<DPP_ROW_ROR(1), 0xf, false>(0.0f, h.y);
+                // lane 0 takes the state leaving lane 15; row_shl:15 finds no source for the other lanes, which bound_ctrl
+                // zeroes: the carry is ready to start pass 1 without a select
+                carry[np].x = dpp_mov<DPP_ROW_SHL(15), 0xf, true>(h.x, h.x);
+                carry[np].y = dpp_mov<DPP_ROW_SHL(15), 0xf, true>(h.y, h.y);
                 // Pin the partial outputs here: otherwise LLVM sinks the whole y accumulation into the
                 // (conditional) store block at the end of the chunk and keeps every C and h value of all 8
                 // state pairs alive (256 VGPRs + AGPR spills).  Also keeps the pairs from being interleaved.
@@ -279,7 +319,8 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
         FWD_PROBE(5);
         float yv[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) yv[t] = y2[t].x + y2[t].y;
+        for (int t = 0; t < T; ++t)   // (plain C is vectorised into v_pk_add_f32 behind three register moves per pair of sums)
+            asm("v_add_f32 %0, %1, %2" : "=v"(yv[t]) : "v"(y2[t].x), "v"(y2[t].y));
         if (HAS_Z) {
             float zv[T];
             load8d<VEC4, DIRS>(zrow, p0, L, row_ok, rev, zv);
