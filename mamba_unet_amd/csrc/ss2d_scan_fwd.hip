@@ -103,6 +103,19 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     const IO *__restrict__ Bg = static_cast<const IO *>(p.B) + (size_t)(b * p.G + g) * bcs;
     const IO *__restrict__ Cg = static_cast<const IO *>(p.C) + (size_t)(b * p.G + g) * bcs;
 
+    // FAST builds store through buffer resources: rows and positions that do not exist are dropped by the range check
+    // instead of being branched around.  (A store under a branch makes the compiler's count of outstanding memory
+    // operations path dependent; it then waits for vmcnt(0) before the prefetched tile is used -- that is, for the
+    // stores issued a moment ago -- which the probes showed as 11 % of a wave's time.)
+    constexpr bool FAST = VEC4 && FULL && !HAS_Z;
+    const int c0_in_g = cb * (NW * 4) + __builtin_amdgcn_readfirstlane(wave) * 4;
+    const int nrow = __builtin_amdgcn_readfirstlane(p.dpg - c0_in_g < 0 ? 0 : (p.dpg - c0_in_g > 4 ? 4 : p.dpg - c0_in_g));
+    const size_t wrow0 = (size_t)b * p.dim + (size_t)g * p.dpg + c0_in_g;
+    const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(static_cast<IO *>(p.out) + wrow0 * L, FAST ? (unsigned)(nrow * L * (int)sizeof(IO)) : 0u);
+    const __amdgpu_buffer_rsrc_t ck_rs = make_rsrc(p.ckpt ? p.ckpt + wrow0 * p.nchunks * 16 : nullptr,
+                                                    FAST && p.ckpt ? (unsigned)(nrow * p.nchunks * 64) : 0u);
+    constexpr unsigned OOB = 0xffffff00u;
+
     // A * log2(e) of the row's 16 states lives in LDS (one ds_read_b64 per pair and chunk): 16 registers that pay for the
     // B/C tile prefetch below without giving up the third wave per SIMD
     f2 carry[NP];
@@ -188,6 +201,22 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     f4 tlo[2], thi[2];
     if (TPRE) tile_fetch(0, tid, tlo, thi);
 
+    // FAST: a chunk's outputs are stored by the NEXT iteration, just before it requests its prefetches.  Stores issued at
+    // the end of an iteration would be the youngest memory operations when the next one waits for its tile and inputs,
+    // and whenever the compiler's vmcnt bookkeeping is conservative (it merges the loop entry with the back edge) that
+    // wait becomes a wait for the stores' acknowledgement.
+    f4 ya = f4{0, 0, 0, 0}, yb = f4{0, 0, 0, 0};
+    unsigned oa = OOB, ob = OOB;
+    auto put_y = [&]() {
+        if (sizeof(IO) == 4) {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ya), out_rs, oa, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, yb), out_rs, ob, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(ya, bf16x4)), out_rs, oa, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(yb, bf16x4)), out_rs, ob, 0, 0);
+        }
+    };
+
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int buf = chunk & 1;
         const int base = chunk * CHUNK;
@@ -229,6 +258,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
             // D*u enters through both halves of the packed accumulator (exact halving; saves zeroing the second half)
 #pragma unroll
             for (int t = 0; t < T; ++t) y2[t] = splat2(uv[t]) * f2{0.5f * Dc, 0.5f * Dc};
+            if (FAST) put_y();
             // u / delta of the next chunk, into the registers just consumed (unconditional: behind the last chunk the
             // clamped address re-reads the row's tail, and a conditional load would bring back a register copy per value)
             fetch_row(urow, p0 + CHUNK, uv);
@@ -257,7 +287,13 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
             finish_dt();
         }
 
-        if (p.ckpt != nullptr && seg == 0 && row_ok) {  // state entering this chunk, for the backward
+        if (FAST) {   // state entering this chunk, for the backward: lane 0 of every row, 64 bytes
+            const unsigned co = seg == 0 ? (unsigned)((row * p.nchunks + chunk) * 64) : OOB;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f4{carry[2 * q].x, carry[2 * q].y, carry[2 * q + 1].x, carry[2 * q + 1].y}),
+                                                       ck_rs, co + 16 * q, 0, 0);
+        } else if (p.ckpt != nullptr && seg == 0 && row_ok) {
             float *ck = p.ckpt + (((size_t)b * p.dim + c) * p.nchunks + chunk) * N;
             if (FULL) {
 #pragma unroll
@@ -327,9 +363,17 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
 #pragma unroll
             for (int t = 0; t < T; ++t) yv[t] *= zv[t] * sigmoidf_fast(zv[t]);
         }
-        store8d<VEC4, DIRS>(orow, p0, L, row_ok, rev, yv);
+        if (FAST) {   // handed to the next iteration, which stores it ahead of its prefetches (see put_y)
+            ya = rev ? f4{yv[3], yv[2], yv[1], yv[0]} : f4{yv[0], yv[1], yv[2], yv[3]};
+            yb = rev ? f4{yv[7], yv[6], yv[5], yv[4]} : f4{yv[4], yv[5], yv[6], yv[7]};
+            oa = p0 < L ? (unsigned)(row * L + (rev ? L - 4 - p0 : p0)) * (unsigned)sizeof(IO) : OOB;
+            ob = p0 + 4 < L ? (unsigned)(row * L + (rev ? L - 8 - p0 : p0 + 4)) * (unsigned)sizeof(IO) : OOB;
+        } else {
+            store8d<VEC4, DIRS>(orow, p0, L, row_ok, rev, yv);
+        }
         FWD_PROBE(6);
     }
+    if (FAST) put_y();
 #ifdef SS2D_FWD_PROBE
     if (g_fwd_probe && lane == 0) {
         unsigned long long *q = g_fwd_probe + ((size_t)blockIdx.x * NW + wave) * (FWD_NPROBE + 1);
