@@ -273,6 +273,16 @@ int ss2d_ln_head_bwd(int in_dtype, int out_dtype, const void *dlogits, const voi
 int ss2d_chan_wgrad(int dtype, const void *P, const void *Q, float *out, int B, int G, int Mb, int Ns, int L, long long spb,
                     long long spg, long long sqb, long long sqg, long long sog, long long soi, long long soj, void *stream);
 
+/* x_proj (mamba_sys.py:407), dt_proj (:420) and their input gradients as ONE product over channel-major operands:
+ *   Y[b*syb + g*syg + m*L + l] = sum_{k<K} W[g*swg + m*ldw + k] * X[b*sxb + g*sxg + k*L + l],   m < M, l < L
+ * (x_proj: W = x_proj_weight, X = xs; its dX: W = weight^T, X = d_x_dbl; dt_proj: W = dt_projs_weight, X = the dts rows of
+ * x_dbl; its d_dts: W = weight^T, X = d_delta).  bf16 in, fp32 accumulation (MFMA), bf16 out, Y WRITTEN.  X and Y rows are L
+ * apart and may be row ranges of wider blocks (strides).  L, the strides of X / Y and their base addresses must be
+ * multiples of 4 elements; ldw >= K and the group stride swg multiples of 8, W 16-byte aligned, and the columns
+ * K .. ldw-1 of W must hold zeros.  SS2D_DTYPE_BF16 only (fp32 callers use the BLAS library). */
+int ss2d_chan_gemm(int dtype, const void *W, const void *X, void *Y, int B, int G, int M, int K, int ldw, int L, long long swg,
+                   long long sxb, long long sxg, long long syb, long long syg, void *stream);
+
 /* Column sums out[j] = sum_r x[r*ldx + j] (fp32) of a (rows, M) matrix in dtype: autograd's bias gradient of the Linears
  * that have a bias (`concat_back_dim`, mamba_sys.py:774-778, applied :835).  Deterministic (per-workgroup partial rows in
  * `workspace`, ss2d_colsum_workspace_floats(M) floats, added in a fixed order); out is WRITTEN. */

@@ -1,0 +1,185 @@
+// The projections between the depthwise convolution and the scan, and their input gradients, for gfx950 (bf16 MFMA):
+//   x_proj   (mamba_sys.py:407)  x_dbl[b][k][c][l]  = sum_d W[k][c][d]  * xs[b][k][d][l]
+//            its input gradient  dxs[b][k][d][l]    = sum_c W[k][c][d]  * d_x_dbl[b][k][c][l]        (W given transposed)
+//   dt_proj  (mamba_sys.py:420)  delta[b][k][d][l]  = sum_r Wd[k][d][r] * dts[b][k][r][l]
+//            its input gradient  d_dts[b][k][r][l]  = sum_d Wd[k][d][r] * d_delta[b][k][d][l]        (Wd given transposed)
+// All four are   Y[b][g] (M x L) = W[g] (M x K) . X[b][g] (K x L)   with X and Y CHANNEL-major (a row = one channel, the L
+// positions contiguous) -- the layout the scan wants on both sides.  For the MFMA the contraction index k must be the
+// fast index of both operands inside a lane; W has it (rows of K), X has the positions there instead.  The library runs
+// these as B*G small transposed GEMMs at 30-60 us each whatever the size (tools/proj_gemm_bench.py).  Here:
+//   * a workgroup (4 waves) owns 96 rows of W and 128 positions of one (b, g); K is walked in chunks of 64 or 32;
+//   * the X chunk is brought in as it lies in memory (rows of 256 bytes, coalesced 16-byte pieces) and read back with
+//     ds_read_b64_tr_b16: per 16 lanes a 4 (k) x 16 (position) block, delivered position-per-lane with the four k in a
+//     lane's register pair -- the B operand of v_mfma_f32_32x32x16_bf16 without a transposing pass;
+//   * LDS rows are 320 bytes apart (4 consecutive k rows x 64 bytes of one 32-lane half fall on 64 different banks);
+//   * the next chunk's pieces are in flight (registers) while the current one is multiplied; one barrier per chunk;
+//   * the 96 x 128 result goes through LDS once more so that the stores are whole 256-byte rows.
+#include "ss2d_common.h"
+#include "../../include/ss2d.h"
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct CgParams {
+    const bf16 *W, *X;
+    bf16 *Y;
+    long long swg, sxb, sxg, syb, syg;   // element strides: W per group; X, Y per batch entry and per group (rows are L apart)
+    int B, G, M, K, ldw, L;              // W rows are ldw >= K apart; ldw % 8 == 0 and columns K .. ldw-1 hold zeros
+    int mblocks, ntiles;
+};
+
+constexpr int BM = 96, BN = 128;
+constexpr int XROW = 2 * BN + 64;                            // bytes between LDS rows of the X chunk
+constexpr int YROW = 2 * BN + 16;                            // result image [96][128] bf16
+constexpr int cg_stage_bytes(int kc) { return kc * XROW + BM * (2 * kc + 16); }
+
+// V16: rows of X / Y are 16-byte aligned (L % 8 == 0): 16-byte pieces; otherwise 8-byte pieces (L % 4 == 0).
+// KC: rows of K per chunk.  64 for a long contraction (x_proj forward: fewer barriers and waits per byte), 32 for a short
+// one (the input gradients, dt_proj: half the LDS, four workgroups per CU instead of two -- these are bound by their
+// stores).  Measured both ways at every stage (scratch timings in DESIGN.md).
+template <bool V16, int KC>
+__global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
+    constexpr int WROW = 2 * KC + 16, XBYTES = KC * XROW, STAGE = cg_stage_bytes(KC);
+    constexpr int WPR = KC / 8, NWP = (BM * WPR + 255) / 256;    // 16-byte pieces per W row, per thread
+    static_assert(BM * YROW <= 2 * STAGE, "the result image reuses the chunk buffers");
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+    int blk = blockIdx.x;
+    const int nt = blk % p.ntiles; blk /= p.ntiles;
+    const int mb = blk % p.mblocks; blk /= p.mblocks;
+    const int g = blk % p.G, b = blk / p.G;
+    const int l0 = nt * BN, m0 = mb * BM, L = p.L;
+    const bf16 *__restrict__ Xg = p.X + (size_t)b * p.sxb + (size_t)g * p.sxg;
+    const bf16 *__restrict__ Wg = p.W + (size_t)g * p.swg + (size_t)m0 * p.ldw;
+    bf16 *__restrict__ Yg = p.Y + (size_t)b * p.syb + (size_t)g * p.syg + (size_t)m0 * L;
+    const int nchunks = (p.K + KC - 1) / KC;
+
+    // this thread's pieces of a chunk (row / column fixed over the chunks)
+    constexpr int XPB = V16 ? 16 : 8, XPR = 2 * BN / XPB, NXP = KC * XPR / 256, XE = XPB / 2;   // piece bytes, pieces per row, per thread
+    typedef unsigned xpiece_t __attribute__((ext_vector_type(V16 ? 4 : 2)));
+    xpiece_t xr[NXP];
+    u32x4 wr[NWP];
+    auto load_chunk = [&](int c) {
+        // never a guarded load: the address is clamped to element 0 and the value masked
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) {
+            const int id = j * 256 + tid, row = id / XPR, pc = id - row * XPR;
+            const int k = c * KC + row, col = l0 + pc * XE;
+            const bool ok = k < p.K && col < L;
+            const xpiece_t v = *reinterpret_cast<const xpiece_t *>(Xg + (ok ? (size_t)k * L + col : 0));
+            xr[j] = v & (ok ? ~0u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) {
+            const int id = j * 256 + tid, row = id / WPR, pc = id - row * WPR;
+            const int k = c * KC + pc * 8;
+            const bool ok = row < BM && m0 + row < p.M && k < p.ldw;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(Wg + (ok ? (size_t)row * p.ldw + k : 0));
+            wr[j] = v & (ok ? ~0u : 0u);
+        }
+    };
+    auto put_chunk = [&](int s) {
+        unsigned char *xs = lds + s * STAGE, *ws = xs + XBYTES;
+#pragma unroll
+        for (int j = 0; j < NXP; ++j) {
+            const int id = j * 256 + tid, row = id / XPR, pc = id - row * XPR;
+            *reinterpret_cast<xpiece_t *>(xs + row * XROW + pc * XPB) = xr[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) {
+            const int id = j * 256 + tid, row = id / WPR, pc = id - row * WPR;
+            if (BM * WPR % 256 == 0 || row < BM) *reinterpret_cast<u32x4 *>(ws + row * WROW + pc * 16) = wr[j];
+        }
+    };
+
+    f16v acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+
+    // transposed read of the B operand: 16-lane group gq covers positions 32*wave + 16*(gq & 1) .. +15 and the k rows
+    // 8*(gq >> 1) .. +7 of a k-step in two blocks of 4; lane 4q + p of the group addresses row q, positions 4p .. 4p+3
+    const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int xoff = (8 * (gq >> 1) + q) * XROW + (32 * wave + 16 * (gq & 1) + 4 * pp) * 2;
+    const int woff = l32 * WROW + 16 * half;
+
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int s = c & 1;
+        put_chunk(s);                                     // stage s was last read two chunks ago, behind the previous barrier
+        load_chunk(c + 1 < nchunks ? c + 1 : c);          // in flight during the products (the last one is a harmless repeat)
+        __syncthreads();
+        const unsigned char *xs = lds + s * STAGE, *ws = xs + XBYTES;
+#pragma unroll
+        for (int ks = 0; ks < KC / 16; ++ks) {
+            typedef s16x4 __attribute__((address_space(3))) *lp;
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(xs + xoff + (16 * ks) * XROW));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(xs + xoff + (16 * ks + 4) * XROW));
+            const bf16x8 bf = __builtin_bit_cast(bf16x8, s16x8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) {
+                const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ws + mt * 32 * WROW + woff + 32 * ks));
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    // accumulator register e of a 32x32 tile: row (= m) 8*(e/4) + 4*(lane/32) + e%4, column (= position) lane%32
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = 32 * mt + 8 * (e >> 2) + 4 * half + (e & 3);
+            *reinterpret_cast<bf16 *>(lds + m * YROW + (32 * wave + l32) * 2) = (bf16)acc[mt][e];
+        }
+    __syncthreads();
+    constexpr int NYP = BM * XPR / 256;
+#pragma unroll
+    for (int j = 0; j < NYP; ++j) {
+        const int id = j * 256 + tid, row = id / XPR, pc = id - row * XPR;
+        const int col = l0 + pc * XE;
+        if (m0 + row < p.M && col < L)
+            *reinterpret_cast<xpiece_t *>(Yg + (size_t)row * L + col) = *reinterpret_cast<const xpiece_t *>(lds + row * YROW + pc * XPB);
+    }
+}
+
+}  // namespace
+
+extern "C" int ss2d_chan_gemm(int dtype, const void *W, const void *X, void *Y, int B, int G, int M, int K, int ldw, int L,
+                              long long swg, long long sxb, long long sxg, long long syb, long long syg, void *stream) {
+    if (dtype != SS2D_DTYPE_BF16) { ss2d_set_error("chan_gemm: bf16 only (dtype %d)", dtype); return -1; }
+    if (!W || !X || !Y) { ss2d_set_error("chan_gemm: null required pointer"); return -2; }
+    if (B <= 0 || G <= 0 || M <= 0 || K <= 0 || L <= 0 || ldw < K) { ss2d_set_error("chan_gemm: bad size"); return -3; }
+    if (L % 4 || ((sxb | sxg | syb | syg) % 4) || (((uintptr_t)X | (uintptr_t)Y) & 7)) {
+        ss2d_set_error("chan_gemm: L, the block strides of X / Y and their base addresses must be multiples of 4 elements"); return -4; }
+    if (ldw % 8 || swg % 8 || ((uintptr_t)W & 15)) { ss2d_set_error("chan_gemm: W rows must be 16-byte aligned (ldw, group stride multiples of 8)"); return -4; }
+    CgParams p;
+    p.W = static_cast<const bf16 *>(W); p.X = static_cast<const bf16 *>(X); p.Y = static_cast<bf16 *>(Y);
+    p.swg = swg; p.sxb = sxb; p.sxg = sxg; p.syb = syb; p.syg = syg;
+    p.B = B; p.G = G; p.M = M; p.K = K; p.ldw = ldw; p.L = L;
+    p.mblocks = (M + BM - 1) / BM; p.ntiles = (L + BN - 1) / BN;
+    const long long nwg = (long long)B * G * p.mblocks * p.ntiles;
+    if (nwg > 0x7fffffffLL) { ss2d_set_error("chan_gemm: grid too large"); return -6; }
+    const bool v16 = L % 8 == 0 && ((sxb | sxg | syb | syg) % 8) == 0 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0;
+    const bool k64 = K > 128;
+    const void *k = v16 ? (k64 ? (const void *)cm_gemm_kernel<true, 64> : (const void *)cm_gemm_kernel<true, 32>)
+                        : (k64 ? (const void *)cm_gemm_kernel<false, 64> : (const void *)cm_gemm_kernel<false, 32>);
+    static bool attr[4][SS2D_MAX_DEVICES] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SS2D_MAX_DEVICES) dev = 0;
+    const int lds = 2 * cg_stage_bytes(k64 ? 64 : 32), ai = 2 * v16 + k64;
+    if (!attr[ai][dev]) {
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) {
+            ss2d_set_error("chan_gemm: cannot raise the dynamic LDS limit to %d", lds); return -7; }
+        attr[ai][dev] = true;
+    }
+    void *args[] = {&p};
+    const hipError_t e = hipLaunchKernel(k, dim3((unsigned)nwg), dim3(256), args, lds, (hipStream_t)stream);
+    if (e != hipSuccess) { ss2d_set_error("chan_gemm: launch failed: %s", hipGetErrorString(e)); return (int)e; }
+    return 0;
+}

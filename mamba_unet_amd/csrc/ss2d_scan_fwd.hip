@@ -19,6 +19,12 @@
 
 namespace {
 
+// tuning builds: -DSS2D_FWD_WPE=4 asks the register allocator for 4 waves per SIMD (128 registers)
+#ifdef SS2D_FWD_WPE
+#define SS2D_FWD_WAVES __attribute__((amdgpu_waves_per_eu(SS2D_FWD_WPE, SS2D_FWD_WPE)))
+#else
+#define SS2D_FWD_WAVES
+#endif
 constexpr int T = 8;          // items per lane
 constexpr int CHUNK = 128;    // positions per row per chunk = 16 lanes * T
 constexpr int NP = 8;         // state pairs (dstate <= 16; odd/short dstate padded with inert states)
@@ -70,7 +76,7 @@ __device__ unsigned long long *g_fwd_probe;
 //     delta[d, l] = sum_r dt_w[d, r] * dts[r, l]): the chunk's (R, 128) tile is staged in LDS beside B / C, the 16
 //     weight rows of the workgroup's channels once; 8R FMAs per lane and chunk instead of a (B, K*D, L) tensor.
 template <int NW, bool HAS_Z, bool VEC4, bool FULL, typename IO, bool DIRS, bool DT = false>
-__global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p) {
+__global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const ScanFwdParams p) {
     // [buffer][B|C][(pair*4 + quarter)*16 + seg] ; one f4 = (n,t),(n+1,t),(n,t+1),(n+1,t+1)
     __shared__ f4 tile[2][2][NP * 4 * 16];
     __shared__ __align__(16) float dtile[DT ? 2 : 1][DT ? MAXR : 1][DT ? CHUNK : 4];
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
 #ifdef SS2D_FWD_PROBE
     unsigned pacc[FWD_NPROBE] = {};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
-    const unsigned long long tstart = tprev;
+    const unsigned long long tstart = tprev, rstart = __builtin_amdgcn_s_memrealtime();
 #endif
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, seg = lane & 15;
@@ -378,6 +384,8 @@ __global__ __launch_bounds__(NW * 64) void scan_fwd_kernel(const ScanFwdParams p
     if (g_fwd_probe && lane == 0) {
         unsigned long long *q = g_fwd_probe + ((size_t)blockIdx.x * NW + wave) * (FWD_NPROBE + 1);
         for (int i = 0; i < FWD_NPROBE; ++i) q[i] = pacc[i];
+        q[FWD_NPROBE - 2] = rstart;                      // slots 6 / 7: start / end on the 100 MHz device-wide clock
+        q[FWD_NPROBE - 1] = __builtin_amdgcn_s_memrealtime();
         q[FWD_NPROBE] = __builtin_amdgcn_s_memtime() - tstart;
     }
 #endif

@@ -11,7 +11,7 @@ import os as _os
 import torch
 
 from . import _lib
-from .ss2d_ops import chan_wgrad
+from .ss2d_ops import chan_gemm, chan_wgrad
 
 _F32, _BF16 = 0, 1          # include/ss2d.h: SS2D_DTYPE_F32 / SS2D_DTYPE_BF16
 
@@ -283,9 +283,12 @@ class ScanCoreFn(torch.autograd.Function):
                 delta = torch.empty((batch, dim, L), device=dev, dtype=io)
                 rc = lib.ss2d_dt_proj_fwd(code, _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(delta), batch, 4, Dch, R, L, Cx * L, _stream())
                 _lib.check(rc, "ss2d_dt_proj_fwd")
-            else:   # other ranks: library GEMM
-                with torch.autocast("cuda", enabled=False):
-                    delta = torch.matmul(w32.to(io).unsqueeze(0), xd[:, :, :R]).reshape(batch, dim, L)
+            else:   # other ranks (24 / 48 at stages 2 / 3): bf16 MFMA kernel over the dts rows in place, else the library GEMM
+                delta = chan_gemm(w32, xd[:, :, :R]) if io == torch.bfloat16 else None
+                if delta is None:
+                    with torch.autocast("cuda", enabled=False):
+                        delta = torch.matmul(w32.to(io).unsqueeze(0), xd[:, :, :R])
+                delta = delta.reshape(batch, dim, L)
             if not fused_delta:
                 if (Cx * L) % 4 == 0:
                     B_, C_, bcs = xd[:, :, R:R + N], xd[:, :, R + N:], Cx * L

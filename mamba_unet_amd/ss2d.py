@@ -24,7 +24,7 @@ import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import scan_core_fn, scan_merge_fn, selective_scan_fn
 from .ss2d_ops import (apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate,
-                       scan_params)
+                       scan_params, x_proj)
 
 
 class DropPath(nn.Module):
@@ -143,7 +143,7 @@ class SS2D(nn.Module):
         # (plain views / one fused kernel; no index tensor, so the step stays HIP-graph capturable)
         xs2 = dirs_scatter2(x)                                                                  # (B, 2, D, L)
         w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
-        x_dbl = torch.matmul(w_cat.unsqueeze(0), xs2).view(B, 4, Cx, L)                         # group = 2*orientation + rev
+        x_dbl = x_proj(w_cat, xs2).view(B, 4, Cx, L)                                    # group = 2*orientation + rev
         A, Dv, bias, dt_w = scan_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight, regroup=True)
         if xs2.dtype == torch.float32 or (self.bf16_scan_io and xs2.dtype == torch.bfloat16):
             # dt_proj + scan + merge as one node reading x_dbl in place (rows [dts | B | C] of every block)

@@ -190,6 +190,71 @@ def chan_wgrad(P: torch.Tensor, Q: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def chan_gemm(W: torch.Tensor, X: torch.Tensor):
+    """Y (B, G, M, L) bf16 = W (G, M, K) @ X (B, G, K, L) for a channel-major bf16 X whose rows are L apart (row ranges of
+    wider blocks are fine): x_proj, dt_proj and their input gradients (mamba_sys.py:407, :420) on the MFMA kernel of
+    csrc/ss2d_cmgemm.hip.  None when dtype or layout do not qualify (the caller then uses the BLAS library)."""
+    _need_gpu(X, "chan_gemm")
+    B, G, K, L = X.shape
+    M = W.shape[1]
+    if X.dtype != torch.bfloat16 or W.shape[0] != G or W.shape[2] != K or L % 4:
+        return None
+    if not (X.stride(3) == 1 and X.stride(2) == L and X.stride(0) % 4 == 0 and X.stride(1) % 4 == 0) or X.data_ptr() % 8:
+        return None
+    ldw = (K + 7) // 8 * 8
+    Wp = W.to(torch.bfloat16)
+    Wp = torch.nn.functional.pad(Wp, (0, ldw - K)) if ldw != K else Wp.contiguous()
+    Y = torch.empty((B, G, M, L), device=X.device, dtype=torch.bfloat16)
+    with torch.cuda.device(X.device):
+        rc = _lib.load().ss2d_chan_gemm(_BF16, _lib.ptr(Wp), _lib.ptr(X), _lib.ptr(Y), B, G, M, K, ldw, L, M * ldw, X.stride(0),
+                                        X.stride(1), G * M * L, M * L, _stream())
+    _lib.check(rc, "ss2d_chan_gemm")
+    return Y
+
+
+class _XProj(torch.autograd.Function):
+    """x_dbl[b, o] = W[o] @ xs[b, o] (mamba_sys.py:407 with the two directions of an orientation stacked in W).  bf16:
+    forward and dX on the MFMA kernel of csrc/ss2d_cmgemm.hip (26 / 14 / 19 us and 27 / 20 / 12 us at stages 0-2 against
+    the library's 56 / 23 / 24 and 49 / 41 / 30), dW on csrc/ss2d_cmwgrad.hip where it is the faster one (long rows);
+    fp32 and odd layouts: the library's batched GEMM."""
+
+    @staticmethod
+    def forward(ctx, w, xs):
+        if torch.is_autocast_enabled():
+            xs = xs.to(torch.get_autocast_dtype("cuda"))
+        w2 = w.to(xs.dtype)
+        ctx.save_for_backward(w2, xs)
+        ctx.w_dtype = w.dtype
+        y = chan_gemm(w2, xs) if xs.dtype == torch.bfloat16 else None
+        if y is None:
+            with torch.autocast("cuda", enabled=False):
+                y = torch.matmul(w2.unsqueeze(0), xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        w2, xs = ctx.saved_tensors
+        g = g.to(xs.dtype)
+        g = g if g.is_contiguous() else g.contiguous()
+        dxs = dw = None
+        with torch.autocast("cuda", enabled=False):
+            if ctx.needs_input_grad[1]:
+                dxs = chan_gemm(w2.transpose(1, 2), g) if g.dtype == torch.bfloat16 else None
+                if dxs is None:
+                    dxs = torch.matmul(w2.transpose(1, 2).unsqueeze(0), g)
+            if ctx.needs_input_grad[0]:
+                dw = chan_wgrad(g, xs) if g.dtype == torch.bfloat16 and g.shape[-1] >= 512 else None
+                if dw is None:
+                    dw = torch.matmul(g, xs.transpose(2, 3)).sum(0, dtype=torch.float32)
+                dw = dw.to(ctx.w_dtype)
+        return dw, dxs
+
+
+def x_proj(w: torch.Tensor, xs: torch.Tensor) -> torch.Tensor:
+    """w (G, C, D), xs (B, G, D, L) -> (B, G, C, L): the x_proj of mamba_sys.py:407 for channel-major activations."""
+    return _XProj.apply(w, xs)
+
+
 def colsum(g: torch.Tensor) -> torch.Tensor:
     """fp32 sum over all leading axes of g[..., M] (a Linear's bias gradient), csrc/ss2d_colsum.hip: deterministic, and
     unlike torch's multi-block reduction it replays correctly inside a captured HIP graph."""

@@ -473,3 +473,41 @@ def test_chan_wgrad_mfma(B, G, M, N, L, dtype):
     want = torch.einsum("bgml,bgnl->gmn", Pw[:, :, 8:].double(), Qw[:, :, :N].double())
     assert rel_l2(got.cpu(), want) < 1e-5
     assert chan_wgrad(Pd[..., :L - 1], Qd[..., :L - 1]) is None        # rows no longer L apart: the caller falls back
+
+
+@pytest.mark.parametrize("B,G,M,K,L", [(3, 2, 76, 192, 3136), (2, 2, 192, 76, 784), (2, 4, 6, 192, 784), (3, 4, 768, 24, 196),
+                                       (2, 2, 112, 768, 196), (1, 1, 97, 65, 132), (2, 3, 33, 7, 12)])
+def test_chan_gemm_mfma(B, G, M, K, L):
+    """Y[b, g] = W[g] @ X[b, g] for a channel-major bf16 X taken as a row range of a wider block (like the dts rows of
+    x_dbl): x_proj / dt_proj and their input gradients, against an fp64 product of the same bf16 values."""
+    from mamba_unet_amd.ss2d_ops import chan_gemm
+    gen = torch.Generator().manual_seed(M * 7 + K + L)
+    W = (torch.randn(G, M, K, generator=gen) * 0.2).to(torch.bfloat16)
+    Xw = torch.randn(B, G, K + 8, L, generator=gen).to(torch.bfloat16)
+    Xd = Xw.cuda()[:, :, 4:4 + K]
+    got = chan_gemm(W.cuda(), Xd)
+    assert got is not None and got.shape == (B, G, M, L) and got.dtype == torch.bfloat16
+    want = torch.matmul(W.double().unsqueeze(0), Xw[:, :, 4:4 + K].double())
+    assert rel_l2(got.float().cpu(), want) < 4e-3                     # bf16 rounding of the result only
+    assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    assert chan_gemm(W.cuda().float(), Xd.float()) is None              # fp32: library
+
+
+@pytest.mark.parametrize("dtype,L", [(torch.float32, 784), (torch.bfloat16, 784), (torch.bfloat16, 196), (torch.bfloat16, 49)])
+def test_x_proj_function(dtype, L):
+    """x_proj forward, dX and dW (MFMA kernels in bf16 where the layout allows, library otherwise) against fp64 autograd of
+    the same stored values."""
+    from mamba_unet_amd.ss2d_ops import x_proj
+    gen = torch.Generator().manual_seed(5 + L)
+    w = (torch.randn(2, 76, 192, generator=gen) * 0.1).to(dtype)
+    xs = torch.randn(3, 2, 192, L, generator=gen).to(dtype)
+    g = torch.randn(3, 2, 76, L, generator=gen).to(dtype)
+    wr, xr = w.double().requires_grad_(True), xs.double().requires_grad_(True)
+    yr = torch.matmul(wr.unsqueeze(0), xr)
+    yr.backward(g.double())
+    wd, xd = w.cuda().requires_grad_(True), xs.cuda().requires_grad_(True)
+    y = x_proj(wd, xd)
+    y.backward(g.cuda())
+    tol = 1e-5 if dtype == torch.float32 else 4e-3
+    assert y.dtype == dtype and rel_l2(y.detach().float().cpu(), yr.detach()) < tol
+    assert rel_l2(wd.grad.float().cpu(), wr.grad) < tol and rel_l2(xd.grad.float().cpu(), xr.grad) < tol

@@ -7,7 +7,7 @@ src, pat = sys.argv[1], sys.argv[2]
 depth = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 out = os.path.join(tempfile.gettempdir(), "isa_mix.s")
 subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-Wno-unused-command-line-argument",
-                "-S", "--cuda-device-only", src, "-o", out], check=True)
+                "-S", "--cuda-device-only", *os.environ.get("ISA_DEFS", "").split(), src, "-o", out], check=True)
 s = open(out).read()
 names = [m.group(1) for m in re.finditer(r"^(\w+):\s*; @", s, re.M) if pat in m.group(1)]
 for name in names:

@@ -37,7 +37,21 @@ t = probe.view(-1, NP + 1).double().cpu()
 t = t[t[:, NP] > 0]
 tot = t[:, NP].mean().item()
 names = ["0 loop top", "1 B/C tile: global loads + LDS stores", "2 u/delta prefetch issue + softplus", "3 barrier", "4 checkpoint store",
-         "5 the 8 state pairs", "6 y sum + store", "7 -"]
+         "5 the 8 state pairs", "6 y sum + store (then: start clock)", "7 (end clock)"]
 print("waves %d, mean total %.0f ticks" % (t.shape[0], tot))
 for i, n in enumerate(names):
     print("  %-42s %12.0f  %5.1f %%" % (n, t[:, i].mean().item(), 100 * t[:, i].mean().item() / tot))
+
+# launch rounds: start / end of every wave on the device-wide 100 MHz clock (slots 6, 7)
+st0 = (t[:, 6] - t[:, 6].min()) / 100.0
+en = (t[:, 7] - t[:, 6].min()) / 100.0
+print("span %.1f us (event: %.1f us); core ticks per us: %.0f" % (en.max().item(), ev0.elapsed_time(ev1) * 1e3, (t[:, NP] / (en - st0)).median().item()))
+late = st0 > 0.05 * en.max()
+print("waves starting at once: %d, mean duration %.1f us; later: %d, mean start %.1f us, mean duration %.1f us" % (
+    (~late).sum().item(), (en - st0)[~late].mean().item(), late.sum().item(), st0[late].mean().item() if late.any() else 0,
+    (en - st0)[late].mean().item() if late.any() else 0))
+import numpy as np
+h, edges = np.histogram(st0.numpy(), bins=12)
+print("start-time histogram (us):", [(round(float(e)), int(c)) for e, c in zip(edges[:-1], h)])
+h, edges = np.histogram(en.numpy(), bins=12)
+print("end-time histogram (us):", [(round(float(e)), int(c)) for e, c in zip(edges[:-1], h)])
