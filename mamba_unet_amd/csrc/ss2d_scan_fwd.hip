@@ -191,10 +191,11 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
         }
     };
     auto tile_put = [&](int buf_, int it, const f4 (&lo)[2], const f4 (&hi)[2]) {
-        // slot of (pair, quarter j, segment): segments of quarters 2, 3 are stored 8 places on (sg ^ 8), so that the
-        // sixteen lanes that write one ds_write_b128 phase -- eight segments x the two quarter pairs -- hit sixteen
-        // different 16-byte bank groups (unswizzled, lanes 2k and 2k+1 collide: 10 % of the LDS cycles)
-        const int np = it >> 5, q4 = it & 31, j0 = (q4 & 1) * 2, sg = (q4 >> 1) ^ (j0 * 4);
+        // slot of (pair, quarter j, segment): segments of quarters 2, 3 are stored 4 places on (sg ^ 4).  ds_write_b128
+        // serves 8 consecutive lanes per pass over 32 banks (8 slots of 16 bytes): lanes 2k and 2k+1 -- same segment,
+        // quarters 0 and 2 -- would meet in one slot (10 % of the LDS cycles); with the swizzle the 8 lanes take the slots
+        // 0 4 1 5 2 6 3 7.  The readers (16 lanes = the 16 slots of a 256-byte line, permuted) stay conflict-free.
+        const int np = it >> 5, q4 = it & 31, j0 = (q4 & 1) * 2, sg = (q4 >> 1) ^ (j0 * 2);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             tile[buf_][m][(np * 4 + j0) * 16 + sg] = f4{lo[m].x, hi[m].x, lo[m].y, hi[m].y};
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
                 const f2 A2np = A2s[wave * 4 + row][np];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f4 Bq = tile[buf][0][(np * 4 + j) * 16 + (seg ^ ((j >> 1) * 8))];
+                    const f4 Bq = tile[buf][0][(np * 4 + j) * 16 + (seg ^ ((j >> 1) * 4))];
                     bb[2 * j] = splat2(du[2 * j]) * f2{Bq.x, Bq.y};
                     bb[2 * j + 1] = splat2(du[2 * j + 1]) * f2{Bq.z, Bq.w};
                 }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
                 // pass 2: true states, fused with the C contraction
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f4 Cq = tile[buf][1][(np * 4 + j) * 16 + (seg ^ ((j >> 1) * 8))];
+                    const f4 Cq = tile[buf][1][(np * 4 + j) * 16 + (seg ^ ((j >> 1) * 4))];
                     h = fma2(a[2 * j], h, bb[2 * j]);
                     y2[2 * j] = fma2(f2{Cq.x, Cq.y}, h, y2[2 * j]);
                     h = fma2(a[2 * j + 1], h, bb[2 * j + 1]);
