@@ -40,7 +40,7 @@ constexpr int cg_stage_bytes(int kc) { return kc * XROW + BM * (2 * kc + 16); }
 // V16: rows of X / Y are 16-byte aligned (L % 8 == 0): 16-byte pieces; otherwise 8-byte pieces (L % 4 == 0).
 // KC: rows of K per chunk.  64 for a long contraction (x_proj forward: fewer barriers and waits per byte), 32 for a short
 // one (the input gradients, dt_proj: half the LDS, four workgroups per CU instead of two -- these are bound by their
-// stores).  Measured both ways at every stage (scratch timings in DESIGN.md).
+// stores).  Measured both ways at every stage (tools/chan_gemm_bench.py).
 template <bool V16, int KC>
 __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
     constexpr int WROW = 2 * KC + 16, XBYTES = KC * XROW, STAGE = cg_stage_bytes(KC);
