@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
     static_assert(BM * YROW <= 2 * STAGE, "the result image reuses the chunk buffers");
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
-    int blk = blockIdx.x;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbours in the tile order share cache lines / operands: one XCD's L2
     const int nt = blk % p.ntiles; blk /= p.ntiles;
     const int mb = blk % p.mblocks; blk /= p.mblocks;
     const int g = blk % p.G, b = blk / p.G;

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void cm_wgrad_kernel(const CmParams p) {
     constexpr int EPS = ROWB / sizeof(IO);                       // positions per step: 128 (fp32) or 256 (bf16)
     constexpr int ROWS = (1 + NT) * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
-    int blk = blockIdx.x;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbours in the tile order share cache lines / operands: one XCD's L2
     const int sl = blk % p.slabs4; blk /= p.slabs4;
     const int sg = blk % p.small_groups; blk /= p.small_groups;
     const int bt = blk % p.big_tiles;

@@ -19,7 +19,7 @@ struct DtProjParams {
 
 template <int R, typename IO>
 __global__ __launch_bounds__(256) void dt_proj_fwd_kernel(const DtProjParams p) {
-    int blk = blockIdx.x;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbours in the tile order share cache lines / operands: one XCD's L2
     const int ds = blk % p.dsplit; blk /= p.dsplit;
     const int lt = blk % p.ltiles, bg = blk / p.ltiles, g = bg % p.G;
     const int dlo = ds * p.dchunk, dhi = min(p.D, dlo + p.dchunk);

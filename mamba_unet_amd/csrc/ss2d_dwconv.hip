@@ -116,7 +116,7 @@ template <bool CL, int CD, int TW, typename IO>
 __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const ConvParams p) {
     constexpr int PW = TW + 2, CS = CD + 1, NDL = 256 / TW, NI = CD / NDL;
     __shared__ float s[(TH + 2) * PW * CS];
-    int blk = blockIdx.x;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbours in the tile order share cache lines / operands: one XCD's L2
     const int w0 = (blk % p.tiles_w) * TW; blk /= p.tiles_w;
     const int h0 = (blk % p.tiles_h) * TH; blk /= p.tiles_h;
     const int d0 = (blk % p.tiles_d) * CD, b = blk / p.tiles_d;
@@ -165,7 +165,7 @@ void dwconv_silu_bwd_kernel(const ConvParams p) {
     __shared__ float sx[XH * XW * CS];
     __shared__ float sg[GH * GW * CS];       // ds
     __shared__ float swt[CD * 10];           // 9 taps + bias per channel
-    int blk = blockIdx.x;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbours in the tile order share cache lines / operands: one XCD's L2
     const int w0 = (blk % p.tiles_w) * TW; blk /= p.tiles_w;
     const int ug = blk % p.groups_h; blk /= p.groups_h;
     const int d0 = blk * CD;
