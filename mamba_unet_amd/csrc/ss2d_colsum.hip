@@ -8,7 +8,7 @@
 
 namespace {
 
-constexpr int MAX_WG = 256;
+constexpr int MAX_WG = 512;
 
 // a workgroup = 256 threads = CQ column quads x (256 / CQ) row lanes over a slab of rows
 template <typename IO>
@@ -42,12 +42,26 @@ __global__ __launch_bounds__(256) void colsum_kernel(const IO *__restrict__ x, f
     }
 }
 
+// 64 columns per workgroup; the partial rows are split over 4 row lanes (8 independent loads in flight each), added in a
+// fixed order
 __global__ __launch_bounds__(256) void colsum_finish_kernel(const float *__restrict__ partials, float *__restrict__ out, int M, int nrows) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= M) return;
+    __shared__ float red[256];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6, j = blockIdx.x * 64 + c;
     float s = 0.0f;
-    for (int r = 0; r < nrows; ++r) s += partials[(size_t)r * M + j];
-    out[j] = s;
+    if (j < M) {
+        int r = part;
+        for (; r + 28 < nrows; r += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(r + 4 * u) * M + j];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; r < nrows; r += 4) s += partials[(size_t)r * M + j];
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (part == 0 && j < M) out[j] = (red[c] + red[64 + c]) + (red[128 + c] + red[192 + c]);
 }
 
 }  // namespace
@@ -63,14 +77,14 @@ extern "C" int ss2d_colsum(int dtype, const void *x, float *out, float *workspac
     const int nq = (M + 3) / 4;
     int cq = 1;
     while (cq < nq && cq < 64) cq *= 2;                                     // column quads per pass: a power of two <= 64
-    long long nwg = (rows + 1023) / 1024;
+    long long nwg = (rows + 127) / 128;      // >= 128 rows per workgroup: a few dozen reads per thread, enough workgroups for a 4704-row input
     if (nwg > MAX_WG) nwg = MAX_WG;
     const long long slab = (rows + nwg - 1) / nwg;
     nwg = (rows + slab - 1) / slab;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == SS2D_DTYPE_BF16) ss2d_launch(colsum_kernel<bf16>, dim3((unsigned)nwg), dim3(256), 0, s, static_cast<const bf16 *>(x), workspace, rows, M, ldx, cq, slab, vec);
     else ss2d_launch(colsum_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, s, static_cast<const float *>(x), workspace, rows, M, ldx, cq, slab, vec);
-    ss2d_launch(colsum_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const float *)workspace, out, M, (int)nwg);
+    ss2d_launch(colsum_finish_kernel, dim3((unsigned)((M + 63) / 64)), dim3(256), 0, s, (const float *)workspace, out, M, (int)nwg);
     const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("colsum: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;

@@ -117,9 +117,11 @@ __global__ __launch_bounds__(256) void dwconv_silu_fwd_kernel(const ConvParams p
     constexpr int PW = TW + 2, CS = CD + 1, NDL = 256 / TW, NI = CD / NDL;
     __shared__ float s[(TH + 2) * PW * CS];
     int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbours in the tile order share cache lines / operands: one XCD's L2
+    // channel tiles fastest: on a channel-last side the CD channels of a pixel are a 32- or 64-byte piece of its row, and
+    // the workgroups that hold the other pieces of the same cache lines should run at the same time on the same XCD
+    const int d0 = (blk % p.tiles_d) * CD; blk /= p.tiles_d;
     const int w0 = (blk % p.tiles_w) * TW; blk /= p.tiles_w;
-    const int h0 = (blk % p.tiles_h) * TH; blk /= p.tiles_h;
-    const int d0 = (blk % p.tiles_d) * CD, b = blk / p.tiles_d;
+    const int h0 = (blk % p.tiles_h) * TH, b = blk / p.tiles_h;
     load_x_tile<CL, 1, CD, TW, 1, IO>(p, s, b, d0, h0, w0);
     __syncthreads();
     const int wl = threadIdx.x % TW, dl = threadIdx.x / TW;
@@ -166,9 +168,9 @@ void dwconv_silu_bwd_kernel(const ConvParams p) {
     __shared__ float sg[GH * GW * CS];       // ds
     __shared__ float swt[CD * 10];           // 9 taps + bias per channel
     int blk = xcd_remap(blockIdx.x, gridDim.x);   // neighbours in the tile order share cache lines / operands: one XCD's L2
+    const int d0 = (blk % p.tiles_d) * CD; blk /= p.tiles_d;     // channel tiles fastest (see the forward)
     const int w0 = (blk % p.tiles_w) * TW; blk /= p.tiles_w;
-    const int ug = blk % p.groups_h; blk /= p.groups_h;
-    const int d0 = blk * CD;
+    const int ug = blk;
     const int tid = threadIdx.x, wl = tid % TW, dl = tid / TW;
     for (int i = tid; i < CD * 10; i += 256) {
         const int d = i / 10, j = i - d * 10;
