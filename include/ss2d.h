@@ -243,6 +243,16 @@ int ss2d_layernorm_unshuffle_bwd(int in_dtype, int out_dtype, const void *dout, 
                                  const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta,
                                  long long batch, int H, int W, int ps, int D, void *stream);
 
+/* LayerNorm(4C) over the 2x2 neighbourhoods of x (batch, H, W, C), channel-last: row (b, i, j) of out (batch*H/2*W/2, 4C) is
+ * x[b,2i,2j] | x[b,2i+1,2j] | x[b,2i,2j+1] | x[b,2i+1,2j+1], normalised -- PatchMerging2D's gather + norm
+ * (mamba_sys.py:213-221) without the four strided slices and the concatenation.  Even H, W; C % 4 == 0, 4C <= 1536.
+ * _bwd writes dx (batch, H, W, C) completely and ACCUMULATES dgamma / dbeta (4C, fp32; caller zero-fills). */
+int ss2d_layernorm_merge_fwd(int in_dtype, int out_dtype, const void *x, const float *gamma, const float *beta, void *out,
+                             float *mean, float *rstd, long long batch, int H, int W, int C, float eps, void *stream);
+int ss2d_layernorm_merge_bwd(int in_dtype, int out_dtype, const void *dout, const void *x, const float *gamma,
+                             const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta, long long batch,
+                             int H, int W, int C, void *stream);
+
 /* LayerNorm + segmentation head in one pass: the tail of VSSM.up_x4 (mamba_sys.py:859-866) = FinalPatchExpand_X4's
  * rearrange + norm (:262-265), permute to (B, C, H', W') and the bias-free 1x1 Conv2d(C -> classes) `output` (:789):
  *   logits[b, k, h', w'] = sum_c w_head[k][c] * LN(unshuffle(x))[b, h', w', c]       H' = H*ps, W' = W*ps

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "ss2d_seg_loss_stats": (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, ctypes.c_longlong, _vp]),
     "ss2d_seg_loss_bwd": (_i, [_i, _vp, _vp, _i, _vp, _vp, _i, _i, ctypes.c_longlong, _vp]),
     "ss2d_layernorm_unshuffle_bwd": (_i, [_i, _i] + [_vp] * 8 + [ctypes.c_longlong, _i, _i, _i, _i, _vp]),
+    "ss2d_layernorm_merge_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, ctypes.c_float, _vp]),
+    "ss2d_layernorm_merge_bwd": (_i, [_i, _i] + [_vp] * 8 + [ctypes.c_longlong, _i, _i, _i, _vp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

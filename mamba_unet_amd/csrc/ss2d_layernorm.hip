@@ -21,14 +21,25 @@ struct LNParams {
     int D;
     float eps;
     int ps, psH, psW;   // ps > 0: rows are gathered through a ps x ps pixel un-shuffle of x (B, psH, psW, ps*ps*D)
+                        // ps = -2: rows are the 2x2 neighbourhoods of x (B, psH, psW, D/4) (PatchMerging2D)
 };
 
 // Element offset in x (and dx) of normalised row r.  Plain: r * D.  Un-shuffle (the einops pattern
 // 'b h w (p1 p2 c) -> b (h p1) (w p2) c' of mamba_sys.py:244, :262): output row (b, h*ps + p1, w*ps + p2) is the
 // c-long run ((((b*H + h)*W + w)*ps + p1)*ps + p2) * c of the expand Linear's output -- the rearranging copy (231 MB
 // each way in front of the last LayerNorm) becomes address arithmetic.
+// Merge (mamba_sys.py:213-219, x0 | x1 | x2 | x3 = the (0,0), (1,0), (0,1), (1,1) pixels of a 2x2 neighbourhood,
+// concatenated): the row's base is pixel (2i, 2j); ln_chunk_off adds the pixel of the chunk's quarter.
 __device__ __forceinline__ long long ln_row_off(const LNParams &p, long long r) {
     if (p.ps == 0) return r * p.D;
+    if (p.ps < 0) {
+        const int w2 = p.psW >> 1, h2 = p.psH >> 1;
+        const int j = (int)(r % w2);
+        const long long t = r / w2;
+        const int i = (int)(t % h2);
+        const long long b = t / h2;
+        return ((b * p.psH + 2 * i) * p.psW + 2 * j) * (long long)(p.D >> 2);
+    }
     const int W4 = p.psW * p.ps, H4 = p.psH * p.ps;
     const int w4 = (int)(r % W4);
     const long long t = r / W4;
@@ -36,6 +47,13 @@ __device__ __forceinline__ long long ln_row_off(const LNParams &p, long long r) 
     const long long b = t / H4;
     const int h = h4 / p.ps, p1 = h4 % p.ps, w = w4 / p.ps, p2 = w4 % p.ps;
     return ((((b * p.psH + h) * p.psW + w) * p.ps + p1) * p.ps + p2) * (long long)p.D;
+}
+
+// element offset of four-element chunk c of a row, relative to ln_row_off
+__device__ __forceinline__ int ln_chunk_off(const LNParams &p, int c) {
+    if (p.ps >= 0) return 4 * c;
+    const int C = p.D >> 2, e = 4 * c, q = e / C, within = e - q * C;     // quarter q = pixel (q & 1, q >> 1)
+    return ((q & 1) * p.psW + (q >> 1)) * C + within;
 }
 
 // sum over the LW (64 or 32) lanes that share a row
@@ -53,11 +71,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LNParams p) {
     const TI *__restrict__ X = static_cast<const TI *>(p.x);
     TO *__restrict__ O = static_cast<TO *>(p.out);
     f4 g[K], b[K];
+    int co[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int c = lane + LW * k;
         g[k] = c < nchunk ? ld4(p.gamma + 4 * c) : f4{0, 0, 0, 0};
         b[k] = c < nchunk ? ld4(p.beta + 4 * c) : f4{0, 0, 0, 0};
+        co[k] = ln_chunk_off(p, c < nchunk ? c : 0);
     }
     const float invD = 1.0f / (float)D;
     for (long long r = wave0; r < p.rows; r += nwaves) {
@@ -67,7 +87,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LNParams p) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + LW * k;
-            xv[k] = c < nchunk ? ld4(X + xoff + 4 * c) : f4{0, 0, 0, 0};
+            xv[k] = c < nchunk ? ld4(X + xoff + co[k]) : f4{0, 0, 0, 0};
             s += (xv[k].x + xv[k].y) + (xv[k].z + xv[k].w);
         }
         const float mu = wave_sum_ln<LW>(s) * invD;
@@ -102,9 +122,11 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
     const TO *__restrict__ G = static_cast<const TO *>(p.dout);
     TI *__restrict__ DX = static_cast<TI *>(p.dx);
     f4 g[K], ag[K], ab[K];
+    int co[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         const int c = lane + LW * k;
+        co[k] = ln_chunk_off(p, c < nchunk ? c : 0);
         g[k] = c < nchunk ? ld4(p.gamma + 4 * c) : f4{0, 0, 0, 0};
         ag[k] = f4{0, 0, 0, 0};
         ab[k] = f4{0, 0, 0, 0};
@@ -122,7 +144,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
             dn[k] = f4{0, 0, 0, 0};
             if (c < nchunk) {
                 const f4 gv = ld4(G + r * D + 4 * c);
-                nh[k] = (ld4(X + xoff + 4 * c) - mu) * rstd;
+                nh[k] = (ld4(X + xoff + co[k]) - mu) * rstd;
                 dn[k] = gv * g[k];
                 ag[k] += gv * nh[k];
                 ab[k] += gv;
@@ -135,7 +157,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + LW * k;
-            if (c < nchunk) st4(DX + xoff + 4 * c, (dn[k] - m1 - nh[k] * m2) * rstd);
+            if (c < nchunk) st4(DX + xoff + co[k], (dn[k] - m1 - nh[k] * m2) * rstd);
         }
     }
     wg_colsum2<K, NWV, LW>(red, ag, ab, D, p.dgamma, p.dbeta);
@@ -454,6 +476,37 @@ extern "C" int ss2d_layernorm_unshuffle_bwd(int in_dtype, int out_dtype, const v
     p.dout = dout; p.x = x; p.gamma = gamma; p.mean_in = mean; p.rstd_in = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
     p.D = D; p.rows = batch * H * ps * W * ps; p.ps = ps; p.psH = H; p.psW = W;
     return dispatch(true, in_dtype, out_dtype, p, stream, "layernorm_unshuffle_bwd");
+}
+
+// LayerNorm over the 2x2 neighbourhoods of x (B, H, W, C) -> out (B*H/2*W/2, 4C): the gather of PatchMerging2D
+// (mamba_sys.py:213-221: x0 | x1 | x2 | x3, norm) done by the kernel's addressing instead of four strided slices and a cat
+static int check_merge(long long batch, int H, int W, int C, const char *name) {
+    if (batch <= 0 || H <= 0 || W <= 0 || C <= 0 || (H & 1) || (W & 1) || (C & 3)) {
+        ss2d_set_error("%s: needs even H, W and C %% 4 == 0 (batch %lld, H %d, W %d, C %d)", name, batch, H, W, C); return -3; }
+    return 0;
+}
+
+extern "C" int ss2d_layernorm_merge_fwd(int in_dtype, int out_dtype, const void *x, const float *gamma, const float *beta,
+                                        void *out, float *mean, float *rstd, long long batch, int H, int W, int C, float eps,
+                                        void *stream) {
+    if (!x || !gamma || !beta || !out) { ss2d_set_error("layernorm_merge_fwd: null pointer"); return -2; }
+    if ((mean == nullptr) != (rstd == nullptr)) { ss2d_set_error("layernorm_merge_fwd: mean and rstd go together"); return -2; }
+    if (int rc = check_merge(batch, H, W, C, "layernorm_merge_fwd")) return rc;
+    LNParams p{};
+    p.x = x; p.gamma = gamma; p.beta = beta; p.out = out; p.mean = mean; p.rstd = rstd; p.D = 4 * C; p.eps = eps;
+    p.rows = batch * (H / 2) * (W / 2); p.ps = -2; p.psH = H; p.psW = W;
+    return dispatch(false, in_dtype, out_dtype, p, stream, "layernorm_merge_fwd");
+}
+
+extern "C" int ss2d_layernorm_merge_bwd(int in_dtype, int out_dtype, const void *dout, const void *x, const float *gamma,
+                                        const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta,
+                                        long long batch, int H, int W, int C, void *stream) {
+    if (!dout || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta) { ss2d_set_error("layernorm_merge_bwd: null pointer"); return -2; }
+    if (int rc = check_merge(batch, H, W, C, "layernorm_merge_bwd")) return rc;
+    LNParams p{};
+    p.dout = dout; p.x = x; p.gamma = gamma; p.mean_in = mean; p.rstd_in = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.D = 4 * C; p.rows = batch * (H / 2) * (W / 2); p.ps = -2; p.psH = H; p.psW = W;
+    return dispatch(true, in_dtype, out_dtype, p, stream, "layernorm_merge_bwd");
 }
 
 extern "C" int ss2d_ln_head_fwd(int in_dtype, int out_dtype, const void *x, const float *gamma, const float *beta,

@@ -430,13 +430,20 @@ def outnorm_gate(y: torch.Tensor, z: torch.Tensor, weight: torch.Tensor, bias: t
 
 class _LayerNorm(torch.autograd.Function):
     """LayerNorm over the last axis; with ps > 0 over the rows of a ps x ps pixel un-shuffle of x (B, H, W, ps*ps*D):
-    out (B, H*ps, W*ps, D) = norm(rearrange(x, 'b h w (p1 p2 c) -> b (h p1) (w p2) c')), gathered inside the kernel."""
+    out (B, H*ps, W*ps, D) = norm(rearrange(x, 'b h w (p1 p2 c) -> b (h p1) (w p2) c')), gathered inside the kernel;
+    with ps = -2 over the 2x2 neighbourhoods of x (B, H, W, C): out (B, H/2, W/2, 4C) = norm(x0 | x1 | x2 | x3)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps, ps=0):
         _need_gpu(x, "layer_norm")
         io, code = _io(x)
-        if ps:
+        if ps < 0:
+            B, H, W, C = x.shape
+            D = 4 * C
+            x2 = x.to(io)
+            x2 = x2 if x2.is_contiguous() else x2.contiguous()
+            out_shape, rows = (B, H // 2, W // 2, D), B * (H // 2) * (W // 2)
+        elif ps:
             B, H, W, C = x.shape
             D = C // (ps * ps)
             x2 = x.to(io)
@@ -456,7 +463,10 @@ class _LayerNorm(torch.autograd.Function):
         rstd = torch.empty_like(mean)
         lib = _lib.load()
         with torch.cuda.device(x.device):
-            if ps:
+            if ps < 0:
+                rc = lib.ss2d_layernorm_merge_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(out),
+                                                  _lib.ptr(mean), _lib.ptr(rstd), B, H, W, C, float(eps), _stream())
+            elif ps:
                 rc = lib.ss2d_layernorm_unshuffle_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(out),
                                                       _lib.ptr(mean), _lib.ptr(rstd), B, H, W, ps, D, float(eps), _stream())
             else:
@@ -477,7 +487,11 @@ class _LayerNorm(torch.autograd.Function):
         dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(g32.shape))
         lib = _lib.load()
         with torch.cuda.device(g.device):
-            if ps:
+            if ps < 0:
+                B, H, W, C = xshape
+                rc = lib.ss2d_layernorm_merge_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
+                                                  _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), B, H, W, C, _stream())
+            elif ps:
                 B, H, W, _ = xshape
                 rc = lib.ss2d_layernorm_unshuffle_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
                                                       _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), B, H, W, ps, D, _stream())
@@ -531,6 +545,19 @@ def apply_norm_unshuffle(module: torch.nn.Module, x: torch.Tensor, p: int) -> to
             and c <= 1536 and module.weight is not None and module.bias is not None and tuple(module.normalized_shape) == (c,)):
         return _LayerNorm.apply(x, module.weight, module.bias, module.eps, p)
     return apply_norm(module, pixel_unshuffle_cl(x, p))
+
+
+def apply_norm_merge(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """module(cat([x[:, 0::2, 0::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 1::2, 1::2]], -1)) for an nn.LayerNorm over 4C
+    channels (PatchMerging2D, mamba_sys.py:213-221), the 2x2 gather done by the LayerNorm kernel's addressing.  Odd sizes
+    (the reference truncates them) and other norms take the literal path."""
+    B, H, W, C = x.shape
+    if (type(module) is torch.nn.LayerNorm and x.is_cuda and H % 2 == 0 and W % 2 == 0 and C % 4 == 0 and 4 * C <= 1536
+            and module.weight is not None and module.bias is not None and tuple(module.normalized_shape) == (4 * C,)):
+        return _LayerNorm.apply(x, module.weight, module.bias, module.eps, -2)
+    h2, w2 = H // 2, W // 2
+    parts = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
+    return apply_norm(module, torch.cat(parts, dim=-1).view(B, h2, w2, 4 * C))
 
 
 class _DirsScatter2(torch.autograd.Function):

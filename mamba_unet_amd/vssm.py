@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from .ss2d import VSSLayer, VSSLayer_up
-from .ss2d_ops import apply_linear, apply_norm, apply_norm_unshuffle, concat_linear, ln_unshuffle_head
+from .ss2d_ops import apply_linear, apply_norm, apply_norm_merge, apply_norm_unshuffle, concat_linear, ln_unshuffle_head
 
 
 class PatchEmbed2D(nn.Module):
@@ -44,13 +44,10 @@ class PatchMerging2D(nn.Module):
         self.norm = norm_layer(4 * dim)
 
     def forward(self, x):
-        B, H, W, C = x.shape
-        h2, w2 = H // 2, W // 2
+        H, W = x.shape[1], x.shape[2]
         if (H % 2) or (W % 2):
             print(f"Warning, x.shape {x.shape} is not match even ===========", flush=True)
-        parts = [x[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
-        x = torch.cat(parts, dim=-1).view(B, h2, w2, 4 * C)
-        return apply_linear(self.reduction, apply_norm(self.norm, x))
+        return apply_linear(self.reduction, apply_norm_merge(self.norm, x))
 
 
 class PatchExpand(nn.Module):

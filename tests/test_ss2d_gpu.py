@@ -511,3 +511,32 @@ def test_x_proj_function(dtype, L):
     tol = 1e-5 if dtype == torch.float32 else 4e-3
     assert y.dtype == dtype and rel_l2(y.detach().float().cpu(), yr.detach()) < tol
     assert rel_l2(wd.grad.float().cpu(), wr.grad) < tol and rel_l2(xd.grad.float().cpu(), xr.grad) < tol
+
+
+@pytest.mark.parametrize("B,H,W,C,dtype", [(2, 56, 56, 96, torch.float32), (3, 28, 28, 192, torch.bfloat16), (2, 14, 14, 384, torch.float32),
+                                            (1, 6, 10, 8, torch.float32), (2, 7, 14, 96, torch.float32)])
+def test_layernorm_merge_gather(B, H, W, C, dtype):
+    """PatchMerging2D's 2x2 gather + LayerNorm(4C) by the kernel's addressing (mamba_sys.py:213-221) against the literal
+    slices + cat + fp64 LayerNorm, forward, dx, dgamma, dbeta; an odd size takes the literal path of the reference."""
+    from mamba_unet_amd.ss2d_ops import apply_norm_merge
+    gen = torch.Generator().manual_seed(H * W + C)
+    ln = torch.nn.LayerNorm(4 * C)
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(4 * C, generator=gen)); ln.bias.copy_(torch.randn(4 * C, generator=gen))
+    x = torch.randn(B, H, W, C, generator=gen).to(dtype)
+    h2, w2 = H // 2, W // 2
+    g = torch.randn(B, h2, w2, 4 * C, generator=gen).to(dtype)
+    ref = torch.nn.LayerNorm(4 * C).double()
+    ref.load_state_dict({k: v.double() for k, v in ln.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    parts = [xr[:, i::2, j::2, :][:, :h2, :w2, :] for (i, j) in ((0, 0), (1, 0), (0, 1), (1, 1))]
+    yr = ref(torch.cat(parts, -1))
+    yr.backward(g.double())
+    ln = ln.cuda()
+    xd = x.cuda().requires_grad_(True)
+    y = apply_norm_merge(ln, xd)
+    y.backward(g.cuda())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert y.shape == (B, h2, w2, 4 * C)
+    assert rel_l2(y.detach().float().cpu(), yr.detach()) < tol and rel_l2(xd.grad.float().cpu(), xr.grad) < tol
+    assert rel_l2(ln.weight.grad.cpu(), ref.weight.grad) < tol and rel_l2(ln.bias.grad.cpu(), ref.bias.grad) < tol
