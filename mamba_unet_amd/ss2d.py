@@ -23,7 +23,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import scan_core_fn, scan_merge_fn, selective_scan_fn
-from .ss2d_ops import (apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate,
+from .ss2d_ops import (GradHalves, split_halves, apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate,
                        scan_params, x_proj)
 
 
@@ -183,11 +183,18 @@ class SS2D(nn.Module):
     def forward(self, x: torch.Tensor, **kwargs):
         D = self.d_inner
         xz = apply_linear(self.in_proj, x)                                         # (B, H, W, 2D)
-        xh, z = torch.split(xz, D, dim=-1)     # views; split's backward is one cat instead of two zero-fills + add
-        xc = dwconv3x3_silu(xh, self.conv2d.weight, self.conv2d.bias, channel_last_in=True)
-        if self.forward_core == self.forward_corev0 and isinstance(self.out_norm, nn.LayerNorm):
+        fused_gate = self.forward_core == self.forward_corev0 and isinstance(self.out_norm, nn.LayerNorm)
+        if fused_gate and xz.is_cuda:
+            # views whose gradients are written into the halves of ONE d(xz) buffer by the two consumers below
+            halves = GradHalves()
+            xh, z = split_halves(xz, halves)
+        else:
+            halves = None
+            xh, z = torch.split(xz, D, dim=-1)     # views; split's backward is one cat instead of two zero-fills + add
+        xc = dwconv3x3_silu(xh, self.conv2d.weight, self.conv2d.bias, channel_last_in=True, holder=halves)
+        if fused_gate:
             # out_norm, SiLU(z) and the product in one kernel (:452 + :561)
-            y = outnorm_gate(self._scan_core(xc), z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps)
+            y = outnorm_gate(self._scan_core(xc), z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, holder=halves)
         else:
             y = self.forward_core(xc)
             y = y * F.silu(z)

@@ -84,9 +84,47 @@ class _CrossMerge(torch.autograd.Function):
         return dys.to(ctx.in_dtype), None, None, None
 
 
+class GradHalves:
+    """Shared by the three autograd nodes around one `xz = in_proj(x)` (split, dwconv, out_norm gate): the backward of the
+    gate allocates ONE (.., 2D) gradient buffer and writes dz into its second half, the backward of the convolution writes
+    dx into the first half, and the split's backward hands the buffer on as d(xz) -- instead of two tensors and the
+    58 MB `cat` (stage 0, bf16) that autograd's split backward would make of them."""
+    __slots__ = ("buf",)
+
+    def __init__(self):
+        self.buf = None
+
+
+class _SplitHalves(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xz, holder):
+        ctx.holder, ctx.D = holder, xz.shape[-1] // 2
+        return xz[..., :ctx.D], xz[..., ctx.D:]
+
+    @staticmethod
+    def backward(ctx, gx, gz):
+        D, buf = ctx.D, ctx.holder.buf
+        ctx.holder.buf = None
+        if (buf is not None and gx is not None and gz is not None and gx.dtype == buf.dtype and gz.dtype == buf.dtype
+                and gx.shape[-1] == D and gz.shape[-1] == D and gx.stride() == buf.stride() and gz.stride() == buf.stride()
+                and gx.data_ptr() == buf.data_ptr() and gz.data_ptr() == buf.data_ptr() + D * buf.element_size()):
+            return buf, None                      # both halves were written in place
+        if gx is None:
+            gx = torch.zeros_like(gz)
+        if gz is None:
+            gz = torch.zeros_like(gx)
+        return torch.cat([gx, gz], dim=-1), None
+
+
+def split_halves(xz: torch.Tensor, holder: GradHalves):
+    """xz[..., :D], xz[..., D:] (views), whose gradients can meet in one buffer (see GradHalves)."""
+    return _SplitHalves.apply(xz, holder)
+
+
 class _DwConvSiLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, channel_last_in):
+    def forward(ctx, x, weight, bias, channel_last_in, holder=None):
+        ctx.holder = holder
         _need_gpu(x, "dwconv3x3_silu")
         in_dtype = x.dtype
         io, code = _io(x)
@@ -119,14 +157,18 @@ class _DwConvSiLU(torch.autograd.Function):
         xf, wf, bf = ctx.saved_tensors
         B, D, H, W, cl, ldx, in_dtype, w_dtype, b_dtype, code = ctx.meta
         g = dy.to(xf.dtype).contiguous()
-        dx = torch.empty((B, H, W, D) if cl else (B, D, H, W), device=g.device, dtype=xf.dtype)
+        buf = ctx.holder.buf if ctx.holder is not None else None
+        if cl and buf is not None and buf.dtype == xf.dtype and tuple(buf.shape) == (B, H, W, 2 * D) and D % 4 == 0:
+            dx, lddx = buf[..., :D], 2 * D          # first half of the shared d(xz) buffer (GradHalves)
+        else:
+            dx, lddx = torch.empty((B, H, W, D) if cl else (B, D, H, W), device=g.device, dtype=xf.dtype), D
         dw, db = _lib.zeros_group(g.device, tuple(wf.shape), None if bf is None else tuple(bf.shape))
         with torch.cuda.device(g.device):
             rc = _lib.load().ss2d_dwconv3x3_silu_bwd(code, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(g),
-                                                     _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), B, D, H, W, cl, ldx, D,
+                                                     _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), B, D, H, W, cl, ldx, lddx,
                                                      _stream())
         _lib.check(rc, "ss2d_dwconv3x3_silu_bwd")
-        return dx.to(in_dtype), dw.to(w_dtype), None if db is None else db.to(b_dtype), None
+        return dx.to(in_dtype), dw.to(w_dtype), None if db is None else db.to(b_dtype), None, None
 
 
 def cross_scan(x: torch.Tensor) -> torch.Tensor:
@@ -139,10 +181,10 @@ def cross_merge(ys: torch.Tensor, H: int, W: int, channel_last: bool = True) -> 
     return _CrossMerge.apply(ys, H, W, channel_last)
 
 
-def dwconv3x3_silu(x: torch.Tensor, weight: torch.Tensor, bias, channel_last_in: bool = True) -> torch.Tensor:
+def dwconv3x3_silu(x: torch.Tensor, weight: torch.Tensor, bias, channel_last_in: bool = True, holder=None) -> torch.Tensor:
     """SiLU(depthwise conv3x3(x) + bias) -> (B, D, H, W).  x is (B, H, W, D) (channel_last_in; may be a
-    channel slice of a wider tensor) or (B, D, H, W).  mamba_sys.py:299-308, :558-559."""
-    return _DwConvSiLU.apply(x, weight, bias, channel_last_in)
+    channel slice of a wider tensor) or (B, D, H, W).  mamba_sys.py:299-308, :558-559.  `holder`: see GradHalves."""
+    return _DwConvSiLU.apply(x, weight, bias, channel_last_in, holder)
 
 
 def linear_wgrad(grad_out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
@@ -373,8 +415,9 @@ def apply_linear(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
 
 class _OutNormGate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, z, gamma, beta, eps):
+    def forward(ctx, y, z, gamma, beta, eps, holder=None):
         _need_gpu(y, "outnorm_gate")
+        ctx.holder = holder
         D = y.shape[-1]
         io, code = _io(y)
         y2 = y.reshape(-1, D)
@@ -412,20 +455,25 @@ class _OutNormGate(torch.autograd.Function):
         g = dout.reshape(rows, D).to(y2.dtype)
         g = g if g.is_contiguous() else g.contiguous()
         dy = torch.empty_like(y2)
-        dz = torch.empty((rows, D), device=g.device, dtype=y2.dtype)
+        if ctx.holder is not None and zdt == y2.dtype and D % 4 == 0:
+            # second half of the shared d(xz) buffer; the convolution's backward fills the first (GradHalves)
+            ctx.holder.buf = torch.empty(tuple(zshape[:-1]) + (2 * D,), device=g.device, dtype=y2.dtype)
+            dz, lddz = ctx.holder.buf[..., D:], 2 * D
+        else:
+            dz, lddz = torch.empty((rows, D), device=g.device, dtype=y2.dtype), D
         dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(b32.shape))
         with torch.cuda.device(g.device):
             rc = _lib.load().ss2d_outnorm_gate_bwd(code, _lib.ptr(g), _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32),
                                                    _lib.ptr(b32), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dy),
-                                                   _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), rows, D, ldz, D, _stream())
+                                                   _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), rows, D, ldz, lddz, _stream())
         _lib.check(rc, "ss2d_outnorm_gate_bwd")
-        return dy.view(yshape).to(ydt), dz.view(zshape).to(zdt), dg.to(gdt), db.to(bdt), None
+        return dy.view(yshape).to(ydt), dz.view(zshape).to(zdt), dg.to(gdt), db.to(bdt), None, None
 
 
-def outnorm_gate(y: torch.Tensor, z: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def outnorm_gate(y: torch.Tensor, z: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, holder=None) -> torch.Tensor:
     """LayerNorm over the last axis of y (weight, bias, eps) times SiLU(z), fused (mamba_sys.py:452 + :561).
-    z may be a channel slice of a wider tensor (the z half of xz).  Output has y's dtype."""
-    return _OutNormGate.apply(y, z, weight, bias, eps)
+    z may be a channel slice of a wider tensor (the z half of xz).  Output has y's dtype.  `holder`: see GradHalves."""
+    return _OutNormGate.apply(y, z, weight, bias, eps, holder)
 
 
 class _LayerNorm(torch.autograd.Function):
