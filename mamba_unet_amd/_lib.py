@@ -97,16 +97,55 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def zeros_group(device, *shapes):
-    """fp32 zero tensors of the given shapes (None -> None) carved out of ONE zero-filled buffer: the accumulated
-    gradients of a backward (dA, dD, dbias ...) then cost one fill launch instead of one each.  Pieces start on
-    256-byte boundaries."""
-    import math
+_ARENA = {}                 # device -> [zero-filled fp32 chunk, floats handed out, capture epoch]
+_ARENA_EPOCH = [0, False]   # bumped whenever the stream's capture state changes between two requests
+_ARENA_FLOATS = 1 << 20     # 4 MB per chunk
+_ARENA_MAX_REQ = 1 << 17    # requests above 512 KB get a buffer (and a fill) of their own
+_ARENA_LOCK = None
+
+
+def zeros_flat(device, n):
+    """n fp32 zeros (1-D).  Small requests are carved out of a zero-filled 4 MB chunk per device, so the ~100 accumulated
+    gradient buffers of a training step (dgamma, dbeta, dA, dD, bias and small weight gradients: float-atomic targets)
+    cost a handful of fill launches instead of one each.  A chunk is never reused -- its pieces must be zero -- and
+    lives as long as any piece does; pieces start on 256-byte boundaries.  A chunk filled outside a HIP-graph capture is
+    not used inside one (its fill would not be replayed) and vice versa."""
+    import threading
     import torch
+    global _ARENA_LOCK
+    if n > _ARENA_MAX_REQ or os.environ.get("SS2D_NO_ZERO_ARENA"):      # (env: A/B switch)
+        return torch.zeros((n,), device=device, dtype=torch.float32)
+    if _ARENA_LOCK is None:
+        _ARENA_LOCK = threading.Lock()
+    need = (n + 63) // 64 * 64
+    key = str(device)
+    with _ARENA_LOCK:          # forward and autograd threads both come here
+        cap = torch.cuda.is_current_stream_capturing()
+        if cap != _ARENA_EPOCH[1]:
+            _ARENA_EPOCH[0] += 1
+            _ARENA_EPOCH[1] = cap
+        slot = _ARENA.get(key)
+        if slot is None or slot[1] + need > _ARENA_FLOATS or slot[2] != _ARENA_EPOCH[0]:
+            slot = _ARENA[key] = [torch.zeros((_ARENA_FLOATS,), device=device, dtype=torch.float32), 0, _ARENA_EPOCH[0]]
+        o = slot[1]
+        slot[1] = o + need
+        return slot[0][o:o + n]
+
+
+def zeros(device, shape):
+    """fp32 zeros of `shape` (see zeros_flat)."""
+    import math
+    return zeros_flat(device, math.prod(shape)).view(shape)
+
+
+def zeros_group(device, *shapes):
+    """fp32 zero tensors of the given shapes (None -> None), one request to zeros_flat for all of them: the accumulated
+    gradients of a backward (dA, dD, dbias ...) share a fill launch.  Pieces start on 256-byte boundaries."""
+    import math
     offs, total = [], 0
     for sh in shapes:
         offs.append(total)
         if sh is not None:
             total += (math.prod(sh) + 63) // 64 * 64
-    buf = torch.zeros((total,), device=device, dtype=torch.float32)
+    buf = zeros_flat(device, total)
     return [None if sh is None else buf[o:o + math.prod(sh)].view(sh) for sh, o in zip(shapes, offs)]

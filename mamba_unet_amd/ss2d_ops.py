@@ -201,7 +201,7 @@ def linear_wgrad(grad_out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
         x2 = x2.contiguous()
     if g2.shape[0] != x2.shape[0]:
         raise ValueError(f"linear_wgrad: {tuple(grad_out.shape)} and {tuple(inp.shape)} disagree on the token axes")
-    dw = torch.zeros((M, N), device=grad_out.device, dtype=torch.float32)
+    dw = _lib.zeros(grad_out.device, (M, N))
     with torch.cuda.device(grad_out.device):
         rc = _lib.load().ss2d_linear_wgrad(code, _lib.ptr(g2), _lib.ptr(x2), _lib.ptr(dw), g2.shape[0], M, N,
                                            g2.stride(0), x2.stride(0), N, _stream())
@@ -223,7 +223,7 @@ def chan_wgrad(P: torch.Tensor, Q: torch.Tensor) -> torch.Tensor:
     if L % 4 or not ok(P) or not ok(Q) or (P.data_ptr() | Q.data_ptr()) % (4 * P.element_size()):
         return None
     code = _BF16 if P.dtype == torch.bfloat16 else _F32
-    out = torch.zeros((G, M, N), device=P.device, dtype=torch.float32)
+    out = _lib.zeros(P.device, (G, M, N))
     wide, narrow, soi, soj, Mb, Ns = (P, Q, N, 1, M, N) if M >= N else (Q, P, 1, N, N, M)
     with torch.cuda.device(P.device):
         rc = _lib.load().ss2d_chan_wgrad(code, _lib.ptr(wide), _lib.ptr(narrow), _lib.ptr(out), B, G, Mb, Ns, L, wide.stride(0),
