@@ -5,6 +5,7 @@
 // workgroup-level LDS reduction and one float atomic per column and workgroup (at most 256 workgroups).
 // Input and output storage types are independent: under bf16 autocast the fp32 residual stream is normalised
 // straight into the bf16 tensor the next GEMM reads (no separate cast pass); dx comes back in the input's type.
+#include <cstdlib>
 #include "ss2d_common.h"
 #include "../../include/ss2d.h"
 
@@ -407,9 +408,220 @@ __global__ __launch_bounds__(NWV * 64) void ln_head_bwd_kernel(const LNParams p,
     }
 }
 
+// ---- up to 4 classes (the ACDC configuration): 8 lanes per row instead of 32.
+// With a row of 96 channels on 32 lanes every row costs six 5-step wave reductions (mean, variance, 4 logits) for 4
+// elements per lane: the kernels were bound by cross-lane instructions (169 / 235 us for 231 MB).  Here a lane owns
+// KC = 3 (4) four-element chunks of its row, a wave works on 8 rows at once, and a sum over the row is 3 DPP adds
+// (quad_perm xor 1, xor 2, row_half_mirror).  gamma is folded into the head weight once per lane:
+//     logits[k] = rstd * (sum_d x_d gw[k][d] - mu * sum_d gw[k][d]) + sum_d beta_d wh[k][d],   gw = gamma * wh.
+// Backward: with gl = dlogits of the row and nh = (x - mu) * rstd, only  anh[k][d] = sum_rows gl[k] nh[d]  and
+// sgl[k] = sum_rows gl[k]  are accumulated; dwh = gamma * anh + beta * sgl, dgamma = sum_k wh[k] anh[k],
+// dbeta = sum_k wh[k] sgl[k] follow at the end of the kernel.
+__device__ __forceinline__ float sum8(float v) {
+    v += dpp_mov<0xB1, 0xf, false>(0.0f, v);      // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E, 0xf, false>(0.0f, v);      // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141, 0xf, false>(0.0f, v);     // row_half_mirror: lane i <- lane 7 - i of its group of 8
+    return v;
+}
+__device__ __forceinline__ float dot4(f4 a, f4 b) { return (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w); }
+
+// element offset of normalised row r (32-bit arithmetic: the host guarantees rows < 2^31)
+__device__ __forceinline__ long long head_row_off(const LNParams &p, unsigned r) {
+    const unsigned W4 = (unsigned)(p.psW * p.ps), H4 = (unsigned)(p.psH * p.ps), ps = (unsigned)p.ps;
+    const unsigned w4 = r % W4, t = r / W4, h4 = t % H4, b = t / H4;
+    const unsigned h = h4 / ps, p1 = h4 - h * ps, w = w4 / ps, p2 = w4 - w * ps;
+    return ((((long long)(b * p.psH + h) * p.psW + w) * ps + p1) * ps + p2) * (long long)p.D;
+}
+
+template <int KC, typename TI, typename TO>
+__global__ __launch_bounds__(256) void ln_head4_fwd_kernel(const LNParams p, const HeadParams hp) {
+    const int l8 = threadIdx.x & 7;
+    const long long row0 = (long long)blockIdx.x * 32 + (threadIdx.x >> 3), stride = (long long)gridDim.x * 32;
+    const int D = p.D, nchunk = D >> 2;
+    const TI *__restrict__ X = static_cast<const TI *>(p.x);
+    TO *__restrict__ LG = static_cast<TO *>(hp.logits);
+    bool act[KC];
+    int cc[KC];
+    f4 gw[4][KC];
+    float sgw[4], cb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sgw[k] = 0.0f; cb[k] = 0.0f; }
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        const int c = l8 + 8 * j;
+        act[j] = c < nchunk;
+        cc[j] = act[j] ? c : 0;
+        const f4 g = act[j] ? ld4(p.gamma + 4 * cc[j]) : f4{0, 0, 0, 0}, b = act[j] ? ld4(p.beta + 4 * cc[j]) : f4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f4 w = (act[j] && k < hp.nc) ? ld4(hp.wh + (size_t)k * D + 4 * cc[j]) : f4{0, 0, 0, 0};
+            gw[k][j] = g * w;
+            sgw[k] += (gw[k][j].x + gw[k][j].y) + (gw[k][j].z + gw[k][j].w);
+            cb[k] += dot4(b, w);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { sgw[k] = sum8(sgw[k]); cb[k] = sum8(cb[k]); }
+    const float invD = 1.0f / (float)D;
+    for (long long r = row0; r - (threadIdx.x >> 3) < p.rows; r += stride) {      // whole waves stay in the loop (DPP sums)
+        const bool rok = r < p.rows;
+        const long long xoff = head_row_off(p, (unsigned)(rok ? r : p.rows - 1));
+        f4 xv[KC];
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const f4 t = ld4(X + xoff + 4 * cc[j]);
+            xv[j] = act[j] ? t : f4{0, 0, 0, 0};
+            s += (xv[j].x + xv[j].y) + (xv[j].z + xv[j].w);
+        }
+        const float mu = sum8(s) * invD;
+        float q = 0.0f, lk[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            const f4 d = act[j] ? xv[j] - mu : f4{0, 0, 0, 0};
+            q += dot4(d, d);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lk[k] += dot4(d, gw[k][j]);     // sum (x - mu) gw = sum x gw - mu sum gw
+        }
+        const float rstd = __builtin_amdgcn_rsqf(sum8(q) * invD + p.eps);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lk[k] = sum8(lk[k]) * rstd + cb[k];
+        if (rok) {
+            if (l8 == 0 && p.mean) { p.mean[r] = mu; p.rstd[r] = rstd; }
+            const long long bi = r / hp.plane, pix = r - bi * hp.plane;
+            const float mine = l8 == 0 ? lk[0] : (l8 == 1 ? lk[1] : (l8 == 2 ? lk[2] : lk[3]));
+            if (l8 < hp.nc) st1(LG + (bi * hp.nc + l8) * hp.plane + pix, mine);
+        }
+    }
+    (void)sgw;
+}
+
+template <int KC, typename TI, typename TO>
+__global__ __launch_bounds__(256) void ln_head4_bwd_kernel(const LNParams p, const HeadParams hp) {
+    __shared__ float red[5 * 128];                 // anh[4][D] | sgl[4] (padded)
+    __shared__ __align__(16) float wsh[4 * 128];   // the head weight (zero rows past nc): read per row instead of held in 48 registers
+    const int l8 = threadIdx.x & 7;
+    const long long row0 = (long long)blockIdx.x * 32 + (threadIdx.x >> 3), stride = (long long)gridDim.x * 32;
+    const int D = p.D, nchunk = D >> 2;
+    const TI *__restrict__ X = static_cast<const TI *>(p.x);
+    const TO *__restrict__ GL = static_cast<const TO *>(hp.glog);
+    TI *__restrict__ DX = static_cast<TI *>(p.dx);
+    for (int i = threadIdx.x; i < 5 * 128; i += 256) red[i] = 0.0f;
+    for (int i = threadIdx.x; i < 4 * 128; i += 256) {
+        const int k = i >> 7, d = i & 127;
+        wsh[i] = (k < hp.nc && d < D) ? hp.wh[(size_t)k * D + d] : 0.0f;
+    }
+    __syncthreads();
+    bool act[KC];
+    int cc[KC];
+    f4 g[KC], anh[4][KC];
+    float sgl[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < KC; ++j) {
+        const int c = l8 + 8 * j;
+        act[j] = c < nchunk;
+        cc[j] = act[j] ? c : 0;
+        g[j] = act[j] ? ld4(p.gamma + 4 * cc[j]) : f4{0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) anh[k][j] = f4{0, 0, 0, 0};
+    }
+    const float invD = 1.0f / (float)D;
+    // the next row's inputs are requested before the current row is worked on (one trip = one HBM round trip otherwise)
+    f4 xn[KC];
+    float mun, rsn, gln[4];
+    long long xoffn;
+    auto fetch = [&](long long r) {
+        const long long rc = r < p.rows ? r : p.rows - 1;
+        xoffn = head_row_off(p, (unsigned)rc);
+        mun = p.mean_in[rc]; rsn = p.rstd_in[rc];
+        const long long bi = rc / hp.plane, pix = rc - bi * hp.plane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gln[k] = ld1(GL + (bi * hp.nc + (k < hp.nc ? k : hp.nc - 1)) * hp.plane + pix);
+#pragma unroll
+        for (int j = 0; j < KC; ++j) xn[j] = ld4(X + xoffn + 4 * cc[j]);
+    };
+    fetch(row0);
+    for (long long r = row0; r - (threadIdx.x >> 3) < p.rows; r += stride) {
+        const bool rok = r < p.rows;
+        const long long xoff = xoffn;
+        const float mu = mun, rstd = rsn;
+        float gl[4];
+        f4 xc[KC];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            gl[k] = (rok && k < hp.nc) ? gln[k] : 0.0f;
+            sgl[k] += gl[k];                        // (every lane of the row counts it: only lane 0's copy is used)
+        }
+#pragma unroll
+        for (int j = 0; j < KC; ++j) xc[j] = xn[j];
+        fetch(r + stride);
+        f4 nh[KC], dn[KC];
+        float s1 = 0.0f, s2 = 0.0f;
+        int wo = 0;
+        asm volatile("" : "+v"(wo));      // keeps the weight reads inside the loop (hoisted, they are 48 registers again)
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            nh[j] = act[j] ? (xc[j] - mu) * rstd : f4{0, 0, 0, 0};
+            f4 dout = *reinterpret_cast<const f4 *>(wsh + wo + 4 * cc[j]) * gl[0];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) dout += *reinterpret_cast<const f4 *>(wsh + wo + k * 128 + 4 * cc[j]) * gl[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) anh[k][j] += nh[j] * gl[k];
+            dn[j] = dout * g[j];
+            s1 += (dn[j].x + dn[j].y) + (dn[j].z + dn[j].w);
+            s2 += dot4(dn[j], nh[j]);
+        }
+        const float m1 = sum8(s1) * invD, m2 = sum8(s2) * invD;
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+            if (act[j] && rok) st4(DX + xoff + 4 * cc[j], (dn[j] - m1 - nh[j] * m2) * rstd);
+    }
+    // ---- the workgroup's sums: LDS float atomics (once per kernel), then one global atomic per column
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KC; ++j)
+        if (act[j])
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(&red[k * 128 + 4 * cc[j] + e], anh[k][j][e]);
+    if (l8 == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(&red[4 * 128 + k], sgl[k]);
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+        const float gd = p.gamma[d], bd = p.beta[d];
+        float dg = 0.0f, db = 0.0f;
+        for (int k = 0; k < hp.nc; ++k) {
+            const float a = red[k * 128 + d], sk = red[4 * 128 + k], w = hp.wh[(size_t)k * D + d];
+            atomicAdd(hp.dwh + (size_t)k * D + d, gd * a + bd * sk);      // dWh[k][d] = sum_rows gl[k] * (nh g + b)
+            dg += w * a;                                                    // dgamma[d] = sum_rows dout[d] nh[d]
+            db += w * sk;                                                   // dbeta[d]  = sum_rows dout[d]
+        }
+        atomicAdd(p.dgamma + d, dg);
+        atomicAdd(p.dbeta + d, db);
+    }
+}
+
 template <typename TI, typename TO>
 int launch_head(bool bwd, const LNParams &p, const HeadParams &hp, hipStream_t s) {
     const int ncp = hp.nc <= 4 ? 4 : (hp.nc <= 10 ? 10 : 16);
+    static const bool old_head = getenv("SS2D_HEAD_WIDE_ROWS") != nullptr;   // A/B: the 32-lanes-per-row kernels, read once
+    if (ncp == 4 && !old_head) {        // 8 lanes per row
+        const int kc = (p.D / 4 + 7) / 8;
+        long long nwg = (p.rows + 31) / 32;
+        const long long cap = bwd ? 768 : 4096;      // backward: one resident round (144 registers: 3 workgroups per CU)
+        if (nwg > cap) nwg = cap;
+        const dim3 grid((unsigned)nwg), block(256);
+        if (!bwd) {
+            if (kc <= 3) ss2d_launch((ln_head4_fwd_kernel<3, TI, TO>), grid, block, 0, s, p, hp);
+            else ss2d_launch((ln_head4_fwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
+        } else {
+            if (kc <= 3) ss2d_launch((ln_head4_bwd_kernel<3, TI, TO>), grid, block, 0, s, p, hp);
+            else ss2d_launch((ln_head4_bwd_kernel<4, TI, TO>), grid, block, 0, s, p, hp);
+        }
+        return ss2d_take_launch_rc();
+    }
     if (!bwd) {
         long long nwg = (p.rows + 255) / 256;      // 64 rows per wave and trip
         if (nwg > 8192) nwg = 8192;
