@@ -53,6 +53,10 @@ __device__ __forceinline__ void flush_tile(const WgradParams &p, float *tile, co
     const int half = lane >> 5, l32 = lane & 31;
     // The waves take turns (plain LDS stores, then read-add-write): float atomics on LDS cost 40 us here.
     // accumulator register e of a 32x32 tile: row = 8*(e/4) + 4*(lane/32) + e%4, column = lane%32
+#ifdef SS2D_WGRAD_NOTURNS
+    if (acc[0][0][0] == 12345.678f) tile[lane] = acc[1][1][1] + acc[2][2][2] + acc[0][2][5] + acc[2][0][7] + acc[1][0][3] + acc[0][1][9] + acc[1][2][11] + acc[2][1][13];
+    return;
+#endif
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -67,10 +71,12 @@ __device__ __forceinline__ void flush_tile(const WgradParams &p, float *tile, co
         }
         __syncthreads();
     }
+#ifndef SS2D_WGRAD_NOATOMICS   // (timing experiments only)
     for (int i = threadIdx.x; i < WT * WT; i += 256) {
         const int m = m0 + i / WT, n = n0 + i % WT;
         if (m < p.M && n < p.N) atomicAdd(p.C + (size_t)m * p.ldc + n, tile[i]);
     }
+#endif
 }
 
 // One pipeline stage = 2*UNR token rows.  Addresses of out-of-range columns are clamped (their products only
@@ -283,6 +289,121 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void w
     flush_tile(p, ctile, acc, m0, n0, lane, wave);
 }
 
+// ---- bf16 operands, LDS-staged.  The kernel above fetches its MFMA operands with 48 two-byte reads per 16 tokens and
+// lane (the contraction index -- the token -- is the slow axis of both matrices), and its four waves each hold the whole
+// 96 x 96 tile for a quarter of the tokens, so they meet in LDS by turns at the end.  Timing experiments
+// (-DSS2D_WGRAD_NOTURNS / -DSS2D_WGRAD_NOATOMICS): of 41 us at the stage-0 in_proj shape the main loop is 17, the turns
+// 15, the atomics 9.  Here:
+//   * the workgroup copies a chunk of 64 token rows x (128 | 96) columns of the two operands to LDS as it lies in memory
+//     (16-byte pieces) and the waves read it back with ds_read_b64_tr_b16, which delivers 4 consecutive tokens of one
+//     column per lane: both MFMA operands without a transposing pass.  The A rows (256 bytes) are padded to 320 bytes
+//     (4 consecutive token rows x 64 bytes start at banks 0 / 16 / 32 / 48), the B rows of 192 bytes = 48 banks fall on
+//     0 / 48 / 32 / 16: both conflict-free;
+//   * wave w owns output rows 32w .. 32w+31 of the 128 x 96 tile for ALL tokens of the workgroup's slab: 48 accumulator
+//     registers instead of 144, no cross-wave sum; its three 32 x 32 results leave as fp32 atomics straight from the
+//     accumulator layout (32 consecutive columns per instruction);
+//   * the next chunk is in flight in registers during the MFMAs; one barrier per chunk.
+// Needs M, N, lda, ldb multiples of 8 and 16-byte aligned operands (the host falls back to the kernel above otherwise).
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int TKC = 64, TM = 128, TN = 96;                  // tokens per chunk, tile rows (A columns), tile columns (B columns)
+constexpr int TAROW = 2 * TM + 64, TBROW = 2 * TN;          // bytes per LDS row
+constexpr int TSTAGE = TKC * (TAROW + TBROW);
+
+__global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p) {
+    __shared__ __align__(16) unsigned char lds[2 * TSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tile = lid % tiles;
+    const int m0 = (tile / p.tiles_n) * TM, n0 = (tile % p.tiles_n) * TN;
+    const long long r0 = (long long)(lid / tiles) * p.slab;
+    long long r1 = r0 + p.slab;
+    r1 = r1 < p.rows ? r1 : p.rows;
+    const bf16 *__restrict__ A = static_cast<const bf16 *>(p.A);
+    const bf16 *__restrict__ B = static_cast<const bf16 *>(p.B);
+    // this thread's pieces of a chunk: 4 of A (64 rows x 16 pieces), 3 of B (64 rows x 12 pieces)
+    u32x4 pa[4], pb[3];
+    int brow[3], bcol[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const int id = j * 256 + tid; brow[j] = id / 12; bcol[j] = (id - brow[j] * 12) * 8; }
+    const int arow = tid >> 4, acol = (tid & 15) * 8;          // piece j: row arow + 16 j
+    auto load_chunk = [&](long long rc) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long long row = rc + arow + 16 * j;
+            const bool ok = row < r1 && m0 + acol < p.M;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(A + (ok ? row * p.lda + m0 + acol : 0));
+            pa[j] = v & (ok ? ~0u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const long long row = rc + brow[j];
+            const bool ok = row < r1 && n0 + bcol[j] < p.N;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(B + (ok ? row * p.ldb + n0 + bcol[j] : 0));
+            pb[j] = v & (ok ? ~0u : 0u);
+        }
+    };
+    auto put_chunk = [&](int s) {
+        unsigned char *as = lds + s * TSTAGE, *bs = as + TKC * TAROW;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4 *>(as + (arow + 16 * j) * TAROW + acol * 2) = pa[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4 *>(bs + brow[j] * TBROW + bcol[j] * 2) = pb[j];
+    };
+    f16v acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+    // transposed read: 16-lane group gq covers columns 16*(gq & 1) .. +15 of a 32-column block and the tokens
+    // 8*(gq >> 1) .. +7 of a 16-token step in two blocks of 4; lane 4q + pp addresses token row q, columns 4pp .. 4pp+3
+    const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int trow = 8 * (gq >> 1) + q, tcol = (16 * (gq & 1) + 4 * pp) * 2;
+    const int aoff = trow * TAROW + 64 * wave + tcol, boff = trow * TBROW + tcol;
+    const bool live = m0 + 32 * wave < p.M;                     // a wave whose rows lie past M multiplies nothing
+    const long long nchunks = r1 > r0 ? (r1 - r0 + TKC - 1) / TKC : 0;
+    if (nchunks > 0) load_chunk(r0);
+    for (long long c = 0; c < nchunks; ++c) {
+        const int s = (int)(c & 1);
+        put_chunk(s);                                              // stage s was last read two chunks ago, behind the previous barrier
+        load_chunk(r0 + (c + 1 < nchunks ? c + 1 : c) * TKC);      // in flight during the MFMAs (the last one is a harmless repeat)
+        __syncthreads();
+        if (live) {
+            typedef s16x4 __attribute__((address_space(3))) *lp;
+            const unsigned char *as = lds + s * TSTAGE + aoff, *bs = lds + s * TSTAGE + TKC * TAROW + boff;
+#pragma unroll
+            for (int ks = 0; ks < TKC / 16; ++ks) {
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(as + 16 * ks * TAROW));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(as + (16 * ks + 4) * TAROW));
+                const bf16x8 af = __builtin_bit_cast(bf16x8, s16x8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w});
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bs + 16 * ks * TBROW + 64 * j));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bs + (16 * ks + 4) * TBROW + 64 * j));
+                    const bf16x8 bf = __builtin_bit_cast(bf16x8, s16x8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+#ifndef SS2D_WGRAD_NOATOMICS   // (timing experiments only)
+    // accumulator register e of a 32x32 block: row = 8*(e/4) + 4*(lane/32) + e%4, column = lane%32
+    if (live && nchunks > 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = n0 + 32 * j + l32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + 32 * wave + 8 * (e >> 2) + 4 * half + (e & 3);
+                if (m < p.M && n < p.N) atomicAdd(p.C + (size_t)m * p.ldc + n, acc[j][e]);
+            }
+        }
+    }
+#endif
+}
+
 }  // namespace
 
 extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float *C, long long rows, int M, int N,
@@ -293,14 +414,34 @@ extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float 
     if (lda < M || ldb < N || ldc < N) { ss2d_set_error("linear_wgrad: leading dimension smaller than the row length"); return -4; }
     WgradParams p;
     p.A = A; p.B = B; p.C = C; p.rows = rows; p.M = M; p.N = N; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    static const bool env_direct = getenv("SS2D_WGRAD_DIRECT") != nullptr;   // A/B against the direct-read bf16 form, read once
+    static const bool env_widen = getenv("SS2D_WGRAD_WIDEN") != nullptr;     // A/B against the fp32-MFMA form, read once
+    const bool use_tr = dtype == SS2D_DTYPE_BF16 && !env_widen && !env_direct && M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+                        ((((uintptr_t)A | (uintptr_t)B) & 15) == 0);
+    long long target_waves = 1024;
+    static const long long env_waves = ss2d_env_ll("SS2D_WGRAD_WAVES", 0);   // tuning knob, read once
+    if (env_waves >= 4 && env_waves <= 65536) target_waves = env_waves;
+    else if (use_tr && (double)rows * (M + N) * 2.0 > 150e6) target_waves = 1536;   // 246 MB final expand: 60 us against 78
+    long long nwg;
+    if (use_tr) {
+        // 128 x 96 tiles, one token slab per workgroup (its four waves split the tile's rows, not the tokens): about
+        // target_waves / 4 workgroups, at least 256 token rows each
+        p.tiles_m = (M + TM - 1) / TM; p.tiles_n = (N + TN - 1) / TN;
+        const int tiles = p.tiles_m * p.tiles_n;
+        long long ks = (target_waves / 4 + tiles - 1) / tiles;
+        const long long max_ks = (rows + 255) / 256;
+        if (ks > max_ks) ks = max_ks;
+        if (ks < 1) ks = 1;
+        p.slab = (rows + ks - 1) / ks;
+        ks = (rows + p.slab - 1) / p.slab;
+        p.ksplit = (int)ks;
+        nwg = ks * tiles;
+    } else {
     p.tiles_m = (M + WT - 1) / WT; p.tiles_n = (N + WT - 1) / WT;
     const int tiles = p.tiles_m * p.tiles_n;
     // token slabs: 4 per workgroup (one per wave), about `target_waves` waves in all, at least 128 rows each.
     // One wave per SIMD on every CU: the fp32 form cannot hold more (298 registers); the bf16 form could hold two
     // (242), but twice the workgroups flush twice the atomics and measured 5-10 % slower.
-    long long target_waves = 1024;
-    static const long long env_waves = ss2d_env_ll("SS2D_WGRAD_WAVES", 0);   // tuning knob, read once
-    if (env_waves >= 4 && env_waves <= 65536) target_waves = env_waves;
     long long ks = (target_waves + tiles - 1) / tiles;
     const long long max_ks = (rows + 127) / 128;
     if (ks > max_ks) ks = max_ks;
@@ -308,11 +449,12 @@ extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float 
     long long slab = (rows + ks - 1) / ks;
     slab = (slab + 1) / 2 * 2;
     p.slab = slab; p.ksplit = (int)ks;
-    const long long nwg = (ks / 4) * tiles;
+    nwg = (ks / 4) * tiles;
+    }
     if (nwg > 0x7fffffffLL) { ss2d_set_error("linear_wgrad: grid too large"); return -6; }
     hipStream_t s = (hipStream_t)stream;
-    static const bool env_widen = getenv("SS2D_WGRAD_WIDEN") != nullptr;   // A/B against the fp32-MFMA form, read once
-    if (dtype == SS2D_DTYPE_BF16 && !env_widen) ss2d_launch(wgrad_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);   // env: A/B against the fp32-MFMA form
+    if (use_tr) ss2d_launch(wgrad_bf16_tr_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else if (dtype == SS2D_DTYPE_BF16 && !env_widen) ss2d_launch(wgrad_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);   // env: A/B against the fp32-MFMA form
     else if (dtype == SS2D_DTYPE_BF16) ss2d_launch(wgrad_kernel<bf16>, dim3((unsigned)nwg), dim3(256), 0, s, p);
     else ss2d_launch(wgrad_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, s, p);
     const int rc = ss2d_take_launch_rc();
