@@ -19,6 +19,9 @@
 
 namespace {
 
+#ifndef SS2D_FWD_PRIO
+#define SS2D_FWD_PRIO 1     // 0: off, 1: priority falls with progress (-2 % measured), 2: by phase (no gain)
+#endif
 // tuning builds: -DSS2D_FWD_WPE=4 asks the register allocator for 4 waves per SIMD (128 registers)
 #ifdef SS2D_FWD_WPE
 #define SS2D_FWD_WAVES __attribute__((amdgpu_waves_per_eu(SS2D_FWD_WPE, SS2D_FWD_WPE)))
@@ -227,6 +230,16 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int buf = chunk & 1;
         const int base = chunk * CHUNK;
+#if SS2D_FWD_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);      // experiment: the short memory-issuing part of a chunk goes first, the long arithmetic part yields
+#elif SS2D_FWD_PRIO == 1
+        {   // a wave's issue priority falls as it advances: the SIMD arbitrates oldest-first, which lets the waves of a
+            // round leave one after the other (107 / 145 / 190 us) and the SIMD run half empty in between; this way
+            // they advance together and newly arrived waves catch up.  301 -> 295 us.
+            const int qd = (4 * chunk) / p.nchunks;
+            if (qd == 0) __builtin_amdgcn_s_setprio(3); else if (qd == 1) __builtin_amdgcn_s_setprio(2); else if (qd == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         FWD_PROBE(0);
         // ---- stage the chunk's B/C tile (shared by all waves of the workgroup)
         if (TPRE) {
@@ -315,6 +328,9 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
             }
         }
         FWD_PROBE(4);
+#if SS2D_FWD_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
         for (int np = 0; np < NP; ++np) {
             if (FULL || 2 * np < N) {  // wave-uniform
