@@ -164,6 +164,10 @@ int ss2d_dirs_scatter(int dtype, int layout, const void *x, void *xs, int B, int
                       void *stream);
 int ss2d_dirs_gather(int dtype, int layout, const void *ys, void *y, int B, int D, int H, int W, int y_channel_last,
                      void *stream);
+/* y (B, D, H, W) = sum of the four direction slots of ys4 (SS2D_DIRS_MIRROR_FREE_4) and the two orientation slots of ys2
+ * (SS2D_DIRS_MIRROR_FREE_2) in one pass: autograd's sum of the two gradients that reach x in SS2D's backward -- du of the
+ * selective scan (mamba_sys.py:436-442) through CrossScan (:403-404) and the input gradient of x_proj (:407). */
+int ss2d_dirs_gather6(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, void *stream);
 
 /* Depthwise 3x3 conv (pad 1, bias) + SiLU (mamba_sys.py:299-308, :558-559).
  *   x: channel_last_in ? (B, H, W, ldx) with the D channels first (ldx >= D lets it read the x half of

@@ -24,6 +24,7 @@ using TileSmall = Tile<128, 8, 8>;
 
 struct CrossParams {
     const void *in;    // scan: x ; merge: ys   (IO type: fp32 or bf16)
+    const void *in2;   // merge, EXTRA kernels: a second, 2-slot input (row-major | column-major, un-reversed) added to the sum
     void *out;         // scan: xs; merge: y
     int B, D, H, W, tiles_h, tiles_w, tiles_d;
     // slot layout of the direction axis: row-major pair (slot 0, slot rmB), column-major pair (cmA, cmB); revB = the
@@ -117,10 +118,11 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
 }
 
 // sums in fp32 (LDS), one rounding at the end for bf16 output
-template <bool CL, typename IO, typename T>
+template <bool CL, typename IO, typename T, bool EXTRA = false>
 __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
     __shared__ float s[T::TD * T::SD];
     const IO *__restrict__ in = static_cast<const IO *>(p.in);
+    const IO *__restrict__ in2 = static_cast<const IO *>(p.in2);
     IO *__restrict__ out = static_cast<IO *>(p.out);
     int b, d0, h0, w0;
     tile_coords<T>(p, b, d0, h0, w0);
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
     const int sB = four ? 4 : p.nslots;
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += UB) {
-        float v[UB], v2[UB];
+        float v[UB], v2[UB], v4[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             int d, h, w;
@@ -141,18 +143,20 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
             v[u] = ld1(in + (((size_t)b * p.nslots + 0) * D + dc) * L + pp);
             // with two slots rmB is 0: the same element again, not added
             v2[u] = ld1(in + (((size_t)b * sB + p.rmB) * D + dc) * L + (p.revB ? L - 1 - pp : pp));
+            if (EXTRA) v4[u] = ld1(in2 + (((size_t)b * 2 + 0) * D + dc) * L + pp);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             int d, h, w;
             dec_row<T, 1>(tid + (it0 + u) * 256, d, h, w);
-            s[d * T::SD + h * T::SW + w] = four ? v[u] + v2[u] : v[u];
+            const float r = four ? v[u] + v2[u] : v[u];
+            s[d * T::SD + h * T::SW + w] = EXTRA ? r + v4[u] : r;
         }
     }
     __syncthreads();
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += UB) {
-        float v1[UB], v3[UB];
+        float v1[UB], v3[UB], v5[UB];
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             int d, h, w;
@@ -161,14 +165,16 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
             const size_t q = (size_t)wc * H + hc;
             v1[u] = ld1(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * L + q);
             v3[u] = ld1(in + (((size_t)b * sB + p.cmB) * D + dc) * L + (p.revB ? L - 1 - q : q));
+            if (EXTRA) v5[u] = ld1(in2 + (((size_t)b * 2 + 1) * D + dc) * L + q);
         }
         // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             int d, h, w;
             dec_col<T, 1>(tid + (it0 + u) * 256, d, h, w);
-            const float acc = s[d * T::SD + h * T::SW + w] + v1[u];
-            s[d * T::SD + h * T::SW + w] = four ? acc + v3[u] : acc;
+            float acc = s[d * T::SD + h * T::SW + w] + v1[u];
+            acc = four ? acc + v3[u] : acc;
+            s[d * T::SD + h * T::SW + w] = EXTRA ? acc + v5[u] : acc;
         }
     }
     __syncthreads();
@@ -250,10 +256,11 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
     }
 }
 
-template <bool CL, typename IO, typename T>
+template <bool CL, typename IO, typename T, bool EXTRA = false>
 __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams p) {
     __shared__ float s[T::TD * T::SD];
     const IO *__restrict__ in = static_cast<const IO *>(p.in);
+    const IO *__restrict__ in2 = static_cast<const IO *>(p.in2);
     IO *__restrict__ out = static_cast<IO *>(p.out);
     int b, d0, h0, w0;
     tile_coords<T>(p, b, d0, h0, w0);
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
     const bool four = p.nslots == 4;
     const int sB = four ? 4 : p.nslots;
     {
-        f4 v[NIT], v2[NIT];
+        f4 v[NIT], v2[NIT], v4[EXTRA ? NIT : 1];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int d, h, w;
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
             v[it] = ld4(in + (((size_t)b * p.nslots + 0) * D + dc) * L + pp);
             const IO *i2 = in + (((size_t)b * sB + p.rmB) * D + dc) * L;
             v2[it] = ld4(i2 + (p.revB ? L - 4 - pp : pp));
+            if (EXTRA) v4[it] = ld4(in2 + (((size_t)b * 2 + 0) * D + dc) * L + pp);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -280,12 +288,15 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
             dec_row<T, 4>(tid + it * 256, d, h, w);
             const f4 r = p.revB ? rev4(v2[it]) : v2[it];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[d * T::SD + h * T::SW + w + e] = four ? v[it][e] + r[e] : v[it][e];
+            for (int e = 0; e < 4; ++e) {
+                const float a = four ? v[it][e] + r[e] : v[it][e];
+                s[d * T::SD + h * T::SW + w + e] = EXTRA ? a + v4[it][e] : a;
+            }
         }
     }
     __syncthreads();
     {
-        f4 v1[NIT], v3[NIT];
+        f4 v1[NIT], v3[NIT], v5[EXTRA ? NIT : 1];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int d, h, w;
@@ -295,6 +306,7 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
             v1[it] = ld4(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * L + q);
             const IO *i3 = in + (((size_t)b * sB + p.cmB) * D + dc) * L;
             v3[it] = ld4(i3 + (p.revB ? L - 4 - q : q));
+            if (EXTRA) v5[it] = ld4(in2 + (((size_t)b * 2 + 1) * D + dc) * L + q);
         }
         // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
 #pragma unroll
@@ -304,8 +316,9 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
             const f4 r = p.revB ? rev4(v3[it]) : v3[it];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float acc = s[d * T::SD + (h + e) * T::SW + w] + v1[it][e];
-                s[d * T::SD + (h + e) * T::SW + w] = four ? acc + r[e] : acc;
+                float acc = s[d * T::SD + (h + e) * T::SW + w] + v1[it][e];
+                acc = four ? acc + r[e] : acc;
+                s[d * T::SD + (h + e) * T::SW + w] = EXTRA ? acc + v5[it][e] : acc;
             }
         }
     }
@@ -331,17 +344,23 @@ void launch(bool merge, bool cl, bool vec, bool h, dim3 grid, hipStream_t s, con
         if (cl) { if (h) ss2d_launch((K<true, bf16, T>), grid, block, 0, s, p); else ss2d_launch((K<true, float, T>), grid, block, 0, s, p); } \
         else    { if (h) ss2d_launch((K<false, bf16, T>), grid, block, 0, s, p); else ss2d_launch((K<false, float, T>), grid, block, 0, s, p); } \
     } while (0)
+    if (merge && p.in2) {   // 4 + 2 slots -> channel-first image (the one shape the backward needs)
+        if (vec) { if (h) ss2d_launch((cross_merge_vec_kernel<false, bf16, T, true>), grid, block, 0, s, p); else ss2d_launch((cross_merge_vec_kernel<false, float, T, true>), grid, block, 0, s, p); }
+        else     { if (h) ss2d_launch((cross_merge_kernel<false, bf16, T, true>), grid, block, 0, s, p); else ss2d_launch((cross_merge_kernel<false, float, T, true>), grid, block, 0, s, p); }
+        return;
+    }
     if (vec) { if (merge) SS2D_CROSS_LAUNCH(cross_merge_vec_kernel); else SS2D_CROSS_LAUNCH(cross_scan_vec_kernel); }
     else     { if (merge) SS2D_CROSS_LAUNCH(cross_merge_kernel); else SS2D_CROSS_LAUNCH(cross_scan_kernel); }
 #undef SS2D_CROSS_LAUNCH
 }
 
-int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name) {
+int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name,
+        const void *in2 = nullptr) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("%s: unknown dtype %d", name, dtype); return -1; }
     if (!in || !out) { ss2d_set_error("%s: null pointer", name); return -2; }
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
     CrossParams p;
-    p.in = in; p.out = out; p.B = B; p.D = D; p.H = H; p.W = W;
+    p.in = in; p.in2 = in2; p.out = out; p.B = B; p.D = D; p.H = H; p.W = W;
     if (layout == SS2D_DIRS_REFERENCE) { p.nslots = 4; p.rmB = 2; p.cmA = 1; p.cmB = 3; p.revB = 1; }
     else if (layout == SS2D_DIRS_MIRROR_FREE_4) { p.nslots = 4; p.rmB = 1; p.cmA = 2; p.cmB = 3; p.revB = 0; }
     else if (layout == SS2D_DIRS_MIRROR_FREE_2) { p.nslots = 2; p.rmB = 0; p.cmA = 1; p.cmB = 1; p.revB = 0; }
@@ -355,7 +374,7 @@ int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, i
     const dim3 grid((unsigned)n);
     const bool h = dtype == SS2D_DTYPE_BF16;
     const uintptr_t amask = h ? 7 : 15;   // 4 elements
-    const bool vec = (H % 4 == 0) && (W % 4 == 0) && (!cl || D % 4 == 0) && ((((uintptr_t)in | (uintptr_t)out) & amask) == 0);
+    const bool vec = (H % 4 == 0) && (W % 4 == 0) && (!cl || D % 4 == 0) && ((((uintptr_t)in | (uintptr_t)in2 | (uintptr_t)out) & amask) == 0);
     if (small) launch<TileSmall>(merge, cl, vec, h, grid, s, p); else launch<TileBig>(merge, cl, vec, h, grid, s, p);
     const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
@@ -382,4 +401,11 @@ extern "C" int ss2d_dirs_scatter(int dtype, int layout, const void *x, void *xs,
 }
 extern "C" int ss2d_dirs_gather(int dtype, int layout, const void *ys, void *y, int B, int D, int H, int W, int y_channel_last, void *stream) {
     return run(true, y_channel_last != 0, layout, dtype, ys, y, B, D, H, W, stream, "dirs_gather");
+}
+// y (B, D, H, W) = the four direction slots of ys4 (layout SS2D_DIRS_MIRROR_FREE_4) + the two orientation slots of ys2
+// (SS2D_DIRS_MIRROR_FREE_2), one pass: the backward of an SS2D call, where du of the scan (4 slots) and the input gradient
+// of x_proj (2 slots) meet in dx
+extern "C" int ss2d_dirs_gather6(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, void *stream) {
+    if (!ys2) { ss2d_set_error("dirs_gather6: null pointer"); return -2; }
+    return run(true, false, SS2D_DIRS_MIRROR_FREE_4, dtype, ys4, y, B, D, H, W, stream, "dirs_gather6", ys2);
 }

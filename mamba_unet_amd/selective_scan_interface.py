@@ -250,7 +250,8 @@ class ScanCoreFn(torch.autograd.Function):
     FUSE_DELTA = not _os.environ.get("SS2D_NO_FUSE_DELTA")
 
     @staticmethod
-    def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None):
+    def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None):
+        ctx.holder = holder
         if not x_dbl.is_cuda:
             raise RuntimeError("scan_core_fn: GPU tensors required (no CPU path in mamba_unet_amd)")
         batch, K, Cx, L = x_dbl.shape
@@ -347,7 +348,11 @@ class ScanCoreFn(torch.autograd.Function):
                                                         ScanMergeFn.REV_MASK, bcs, _lib.ptr(ws), wsb, _stream())
                 _lib.check(rc, "ss2d_selective_scan_dir_bwd_ws")
             dx = du2 = None
-            if x_dt is not None:      # all four directions' du -> dx in one pass (the adjoint of the scatter)
+            if x_dt is not None and ctx.holder is not None:
+                # left for the scatter node's backward, which adds it to the x_proj input gradient in one 6-slot gather
+                # (ss2d_ops.GradSlots); x gets no gradient from this node then
+                ctx.holder.du = du
+            elif x_dt is not None:      # all four directions' du -> dx in one pass (the adjoint of the scatter)
                 dx = torch.empty((batch, Dch, H, W), device=dev, dtype=io)
                 rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(du), _lib.ptr(dx), batch, Dch, H, W, 0, _stream())
                 _lib.check(rc, "ss2d_dirs_gather")
@@ -366,12 +371,12 @@ class ScanCoreFn(torch.autograd.Function):
             _lib.check(rc, "ss2d_xdbl_grad_pack")
         cast = lambda t, d: None if t is None else t.to(d)  # noqa: E731
         return (cast(du2, u_dt), cast(d_xdbl, xdbl_dt), cast(d_w, w_dt), cast(dA, A_dt), cast(dD, D_dt), cast(dbias, b_dt),
-                None, None, cast(dx, x_dt))
+                None, None, cast(dx, x_dt), None)
 
 
-def scan_core_fn(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None):
+def scan_core_fn(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None):
     """u2 (b, 2*d, l): row-major and column-major copies of x; x_dbl (b, 4, R+2N, l): the x_proj output with rows
     [dts | B | C] per scan group; dt_w (4, d, R); A (4*d, n), D, delta_bias (4*d) -- all in scan-group order
     (row-major, row-major reversed, column-major, column-major reversed).  delta = dt_w @ dts, softplus(delta + bias)
     as in SS2D.  Returns y (b, H, W, d) = CrossMerge of the four scans."""
-    return ScanCoreFn.apply(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x)
+    return ScanCoreFn.apply(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x, holder)

@@ -17,13 +17,15 @@ import math
 from functools import partial
 from typing import Callable
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import scan_core_fn, scan_merge_fn, selective_scan_fn
-from .ss2d_ops import (GradHalves, split_halves, apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate,
+from .ss2d_ops import (GradHalves, GradSlots, split_halves, apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate,
                        scan_params, x_proj)
 
 
@@ -141,13 +143,14 @@ class SS2D(nn.Module):
         Cx = R + 2 * N
         # reference direction k = 2*rev + orientation  ->  scan group 2*orientation + rev: swap the two index bits
         # (plain views / one fused kernel; no index tensor, so the step stays HIP-graph capturable)
-        xs2 = dirs_scatter2(x)                                                                  # (B, 2, D, L)
+        slots = GradSlots() if (x.is_cuda and x.requires_grad and not os.environ.get("SS2D_NO_GATHER6")) else None     # du and d(xs2) meet in one gather (backward)
+        xs2 = dirs_scatter2(x, slots)                                                           # (B, 2, D, L)
         w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
         x_dbl = x_proj(w_cat, xs2).view(B, 4, Cx, L)                                    # group = 2*orientation + rev
         A, Dv, bias, dt_w = scan_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight, regroup=True)
         if xs2.dtype == torch.float32 or (self.bf16_scan_io and xs2.dtype == torch.bfloat16):
             # dt_proj + scan + merge as one node reading x_dbl in place (rows [dts | B | C] of every block)
-            return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x)
+            return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x, holder=slots)
         # the reference's fp32 casts around the scan (:423-426) under autocast
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = dt_proj(dts, dt_w)                                                                # (B, 4, D, L)

@@ -608,12 +608,23 @@ def apply_norm_merge(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
     return apply_norm(module, torch.cat(parts, dim=-1).view(B, h2, w2, 4 * C))
 
 
+class GradSlots:
+    """Shared by the scatter node and the scan node of one SS2D call: the scan's backward leaves its du (B, 4, D, L) here
+    instead of gathering it into a dx of its own, and the scatter's backward adds it to the x_proj input gradient
+    (B, 2, D, L) in ONE 6-slot gather -- instead of two gathers and autograd's sum of their results."""
+    __slots__ = ("du",)
+
+    def __init__(self):
+        self.du = None
+
+
 class _DirsScatter2(torch.autograd.Function):
     """x (B, D, H, W) -> (B, 2, D, H*W): the row-major and the column-major copy only (layout MIRROR_FREE_2)."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, holder=None):
         _need_gpu(x, "dirs_scatter2")
+        ctx.holder = holder
         B, D, H, W = x.shape
         io, code = _io(x)
         xf = x.to(io).contiguous()
@@ -630,16 +641,29 @@ class _DirsScatter2(torch.autograd.Function):
         io, code = _io(dxs)
         g = dxs.to(io).contiguous()
         dx = torch.empty((B, D, H, W), device=g.device, dtype=io)
+        du = None
+        if ctx.holder is not None:
+            du, ctx.holder.du = ctx.holder.du, None
         with torch.cuda.device(g.device):
-            rc = _lib.load().ss2d_dirs_gather(code, 2, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, 0, _stream())
+            if du is not None and du.dtype == io and tuple(du.shape) == (B, 4 * D, H * W) and du.is_contiguous():
+                rc = _lib.load().ss2d_dirs_gather6(code, _lib.ptr(du), _lib.ptr(g), _lib.ptr(dx), B, D, H, W, _stream())
+                du = None
+            else:
+                rc = _lib.load().ss2d_dirs_gather(code, 2, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, 0, _stream())
         _lib.check(rc, "ss2d_dirs_gather")
-        return dx.to(ctx.in_dtype)
+        if du is not None:      # a du this node could not fold in (dtype / shape): gather it the plain way and add
+            dx2 = torch.empty_like(dx)
+            with torch.cuda.device(g.device):
+                rc = _lib.load().ss2d_dirs_gather(code, 1, _lib.ptr(du.to(io).contiguous()), _lib.ptr(dx2), B, D, H, W, 0, _stream())
+            _lib.check(rc, "ss2d_dirs_gather")
+            dx = dx + dx2
+        return dx.to(ctx.in_dtype), None
 
 
-def dirs_scatter2(x: torch.Tensor) -> torch.Tensor:
+def dirs_scatter2(x: torch.Tensor, holder=None) -> torch.Tensor:
     """(B, D, H, W) -> (B, 2, D, H*W): x flattened row-major and column-major -- the two orientations of CrossScan
     (mamba_sys.py:403); the two reversed directions (:404) are read from the same copies by the scan itself."""
-    return _DirsScatter2.apply(x)
+    return _DirsScatter2.apply(x, holder)
 
 
 class _DtProj(torch.autograd.Function):
