@@ -297,6 +297,15 @@ int ss2d_chan_wgrad(int dtype, const void *P, const void *Q, float *out, int B, 
 int ss2d_chan_gemm(int dtype, const void *W, const void *X, void *Y, int B, int G, int M, int K, int ldw, int L, long long swg,
                    long long sxb, long long sxg, long long syb, long long syg, void *stream);
 
+/* The token-major Linears (in_proj / out_proj, mamba_sys.py:298, :337, applied :556, :563; PatchMerging2D.reduction :196,
+ * the expand Linears :243, :261), bf16 on MFMA:
+ *   b_k_major = 0:  C[t*ldc + n] = sum_k A[t*lda + k] * B[n*ldb + k]     (F.linear(x, weight): A = x, B = weight (out, in))
+ *   b_k_major = 1:  C[t*ldc + n] = sum_k A[t*lda + k] * B[k*ldb + n]     (its input gradient: A = dy, B = weight)
+ * t < T, n < N; fp32 accumulation, C WRITTEN in bf16.  N, K and the leading dimensions multiples of 8, operands 16-byte
+ * aligned.  SS2D_DTYPE_BF16 only (fp32 callers use the BLAS library). */
+int ss2d_token_gemm(int dtype, const void *A, const void *B, void *C, long long T, int N, int K, int lda, int ldb, int ldc,
+                    int b_k_major, void *stream);
+
 /* Column sums out[j] = sum_r x[r*ldx + j] (fp32) of a (rows, M) matrix in dtype: autograd's bias gradient of the Linears
  * that have a bias (`concat_back_dim`, mamba_sys.py:774-778, applied :835).  Deterministic (per-workgroup partial rows in
  * `workspace`, ss2d_colsum_workspace_floats(M) floats, added in a fixed order); out is WRITTEN. */

@@ -1,0 +1,173 @@
+// The token-major Linears of the SS2D path (in_proj / out_proj, mamba_sys.py:298, :337; the patch merge / expand Linears
+// :196, :243, :261), forward and input gradient, bf16 on MFMA for gfx950:
+//     C[t][n] = sum_k A[t][k] * Bm[n][k]      (B_KMAJOR = false: forward,  A = x (T x in),  Bm = weight (out x in))
+//     C[t][n] = sum_k A[t][k] * Bm[k][n]      (B_KMAJOR = true:  dX,       A = dy (T x out), Bm = weight (out x in))
+// These are skinny products (K or N is 96 ... 1536 against T = 1176 ... 75264 tokens) that the BLAS library runs at
+// 1.5-2.4 TB/s of their operand bytes at the large-token stages (tools/proj_gemm_bench.py, scratch timings in DESIGN.md);
+// they are bound by memory, not by the MFMA.
+//   * a workgroup (4 waves) owns 128 tokens x 96 output columns; wave w multiplies tokens 32w .. 32w+31; K is walked in
+//     chunks of 32 or 64 that are copied to LDS as they lie in memory (16-byte pieces), the next chunk in flight in registers;
+//   * the A operand (tokens x k, k contiguous) and the forward's weight rows are plain ds_read_b128 fragments; the dX
+//     weight (k x n, n contiguous) is read back with ds_read_b64_tr_b16;
+//   * the 128 x 96 result goes through LDS once more so that the stores are 16-byte pieces of whole rows.
+// Needs K, N and the leading dimensions multiples of 8 and 16-byte aligned operands; the caller (ss2d_ops._Linear) uses the
+// BLAS library otherwise, and for fp32.
+#include "ss2d_common.h"
+#include "../../include/ss2d.h"
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct TgParams {
+    const bf16 *A, *B;
+    bf16 *C;
+    long long T;
+    int N, K, lda, ldb, ldc, tiles_n;
+};
+
+constexpr int GT = 128, GN = 96;                          // tokens, columns per workgroup
+constexpr int BROW_NN = 2 * GN;                           // dX weight chunk [k][96 n]: 192 B = 48 banks, conflict-free for the transposed read
+constexpr int gstage(bool kmajor, int gk) { return GT * (2 * gk + 16) + (kmajor ? gk * BROW_NN : GN * (2 * gk + 16)); }
+constexpr int CROW = 2 * GN + 16;                         // result image [128 t][96 n] bf16
+static_assert(GT * CROW <= 2 * gstage(true, 32) && GT * CROW <= 2 * gstage(false, 32) && 2 * gstage(false, 64) <= 65536, "LDS budget");
+
+// GK: k per chunk.  32 for a short contraction (K <= 256: 35 KB of LDS, four workgroups per CU -- a workgroup is mostly
+// prologue and epilogue there), 64 for a long one (half the barriers).
+template <bool B_KMAJOR, int GK>
+__global__ __launch_bounds__(256) void tok_gemm_kernel(const TgParams p) {
+    constexpr int AROW = 2 * GK + 16, BROW_NT = 2 * GK + 16, ABYTES = GT * AROW;     // bytes per LDS row of the A chunk [128 t][GK k] / the forward's weight chunk [96 n][GK k]
+    constexpr int STAGE = gstage(B_KMAJOR, GK);
+    constexpr int APR = GK / 8, NAP = GT * APR / 256;       // 16-byte pieces per A row, per thread
+    constexpr int NBP = (B_KMAJOR ? GK * 12 : GN * APR) / 256 + (((B_KMAJOR ? GK * 12 : GN * APR) % 256) ? 1 : 0), NBTOT = B_KMAJOR ? GK * 12 : GN * APR;
+    __shared__ __align__(16) unsigned char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int blk = xcd_remap(blockIdx.x, gridDim.x);           // the column tiles of one token block run back to back on one XCD
+    const int nt = blk % p.tiles_n;
+    const long long t0 = (long long)(blk / p.tiles_n) * GT;
+    const int n0 = nt * GN;
+    // this thread's pieces of a chunk: A 128 rows x 8 pieces -> 4; B 768 pieces -> 3
+    u32x4 pa[NAP], pb[NBP];
+    const int arow = tid / APR, acol = (tid % APR) * 8;    // piece j: token row arow + (256 / APR) j, k = acol
+    int brow[NBP], bcol[NBP];
+    bool bon[NBP];
+#pragma unroll
+    for (int j = 0; j < NBP; ++j) {
+        const int id = j * 256 + tid;
+        bon[j] = id < NBTOT;
+        const int ic = bon[j] ? id : 0;
+        if (B_KMAJOR) { brow[j] = ic / 12; bcol[j] = (ic - brow[j] * 12) * 8; }     // [GK k][96 n]: row = k, col = n
+        else { brow[j] = ic / APR; bcol[j] = (ic - brow[j] * APR) * 8; }             // [96 n][GK k]: row = n, col = k
+    }
+    auto load_chunk = [&](int k0) {
+        // never a guarded load: the address is clamped to element 0 and the value masked
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) {
+            const long long t = t0 + arow + (256 / APR) * j;
+            const bool ok = t < p.T && k0 + acol < p.K;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(p.A + (ok ? t * p.lda + k0 + acol : 0));
+            pa[j] = v & (ok ? ~0u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < NBP; ++j) {
+            bool ok;
+            long long off;
+            if (B_KMAJOR) { ok = bon[j] && k0 + brow[j] < p.K && n0 + bcol[j] < p.N; off = (long long)(k0 + brow[j]) * p.ldb + n0 + bcol[j]; }
+            else { ok = bon[j] && n0 + brow[j] < p.N && k0 + bcol[j] < p.K; off = (long long)(n0 + brow[j]) * p.ldb + k0 + bcol[j]; }
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(p.B + (ok ? off : 0));
+            pb[j] = v & (ok ? ~0u : 0u);
+        }
+    };
+    auto put_chunk = [&](int s) {
+        unsigned char *as = lds + s * STAGE, *bs = as + ABYTES;
+#pragma unroll
+        for (int j = 0; j < NAP; ++j) *reinterpret_cast<u32x4 *>(as + (arow + (256 / APR) * j) * AROW + acol * 2) = pa[j];
+#pragma unroll
+        for (int j = 0; j < NBP; ++j)
+            if (bon[j]) *reinterpret_cast<u32x4 *>(bs + brow[j] * (B_KMAJOR ? BROW_NN : BROW_NT) + bcol[j] * 2) = pb[j];
+    };
+    f16v acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+    const int aoff = (32 * wave + l32) * AROW + 16 * half;                 // + 32 bytes per k-step
+    const int boff_nt = l32 * BROW_NT + 16 * half;                          // + 32 rows per column tile, + 32 bytes per k-step
+    // transposed read (dX): 16-lane group gq covers columns 16*(gq & 1) .. +15 of a 32-column tile and the k rows
+    // 8*(gq >> 1) .. +7 of a k-step in two blocks of 4; lane 4q + pp addresses k row q, columns 4pp .. 4pp+3
+    const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    const int boff_nn = (8 * (gq >> 1) + q) * BROW_NN + (16 * (gq & 1) + 4 * pp) * 2;
+    const int nchunks = (p.K + GK - 1) / GK;
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int s = c & 1;
+        put_chunk(s);                                        // stage s was last read two chunks ago, behind the previous barrier
+        load_chunk((c + 1 < nchunks ? c + 1 : c) * GK);      // in flight during the products (the last one is a harmless repeat)
+        __syncthreads();
+        const unsigned char *as = lds + s * STAGE, *bs = as + ABYTES;
+#pragma unroll
+        for (int ks = 0; ks < GK / 16; ++ks) {
+            const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(as + aoff + 32 * ks));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                bf16x8 bf;
+                if (B_KMAJOR) {
+                    typedef s16x4 __attribute__((address_space(3))) *lp;
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bs + boff_nn + 16 * ks * BROW_NN + 64 * j));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bs + boff_nn + (16 * ks + 4) * BROW_NN + 64 * j));
+                    bf = __builtin_bit_cast(bf16x8, s16x8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
+                } else {
+                    bf = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(bs + boff_nt + 32 * j * BROW_NT + 32 * ks));
+                }
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc[j], 0, 0, 0);      // the TRANSPOSED block: rows = columns n, columns = tokens
+            }
+        }
+    }
+    __syncthreads();
+    // accumulator register e of a 32x32 block: row (= column n of the result) 8*(e/4) + 4*(lane/32) + e%4, column (= token)
+    // lane%32 -- four consecutive n of one token per register quad: one 8-byte LDS store
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bf16x4 v = {(__bf16)acc[j][4 * g], (__bf16)acc[j][4 * g + 1], (__bf16)acc[j][4 * g + 2], (__bf16)acc[j][4 * g + 3]};
+            *reinterpret_cast<bf16x4 *>(lds + (32 * wave + l32) * CROW + (32 * j + 8 * g + 4 * half) * 2) = v;
+        }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int id = j * 256 + tid, row = id / 12, pc = id - row * 12;
+        const long long t = t0 + row;
+        const int n = n0 + pc * 8;
+        if (t < p.T && n < p.N) *reinterpret_cast<u32x4 *>(p.C + t * p.ldc + n) = *reinterpret_cast<const u32x4 *>(lds + row * CROW + pc * 16);
+    }
+}
+
+}  // namespace
+
+extern "C" int ss2d_token_gemm(int dtype, const void *A, const void *B, void *C, long long T, int N, int K, int lda, int ldb,
+                               int ldc, int b_k_major, void *stream) {
+    if (dtype != SS2D_DTYPE_BF16) { ss2d_set_error("token_gemm: bf16 only (dtype %d)", dtype); return -1; }
+    if (!A || !B || !C) { ss2d_set_error("token_gemm: null required pointer"); return -2; }
+    if (T <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N || ldb < (b_k_major ? N : K)) { ss2d_set_error("token_gemm: bad size"); return -3; }
+    if (N % 8 || K % 8 || lda % 8 || ldb % 8 || ldc % 8 || ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) != 0)) {
+        ss2d_set_error("token_gemm: N, K, the leading dimensions must be multiples of 8 and the operands 16-byte aligned"); return -4; }
+    TgParams p;
+    p.A = static_cast<const bf16 *>(A); p.B = static_cast<const bf16 *>(B); p.C = static_cast<bf16 *>(C);
+    p.T = T; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.tiles_n = (N + GN - 1) / GN;
+    const long long nwg = ((T + GT - 1) / GT) * p.tiles_n;
+    if (nwg > 0x7fffffffLL) { ss2d_set_error("token_gemm: grid too large"); return -6; }
+    hipStream_t s = (hipStream_t)stream;
+    const bool k64 = K > 256;
+    if (b_k_major) { if (k64) ss2d_launch((tok_gemm_kernel<true, 64>), dim3((unsigned)nwg), dim3(256), 0, s, p); else ss2d_launch((tok_gemm_kernel<true, 32>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
+    else { if (k64) ss2d_launch((tok_gemm_kernel<false, 64>), dim3((unsigned)nwg), dim3(256), 0, s, p); else ss2d_launch((tok_gemm_kernel<false, 32>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
+    const int rc = ss2d_take_launch_rc();
+    if (rc) ss2d_set_error("token_gemm: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}

@@ -6,6 +6,8 @@ from __future__ import annotations
 
 import os as _os
 
+import os
+
 import torch
 
 from . import _lib
@@ -315,9 +317,43 @@ def colsum(g: torch.Tensor) -> torch.Tensor:
     return out
 
 
+_OWN_TOKEN_GEMM = not os.environ.get("SS2D_LIBRARY_LINEAR")      # A/B switch: the token-major Linears on the BLAS library
+
+
+def token_gemm(a: torch.Tensor, w: torch.Tensor, k_major: bool):
+    """a (..., K) bf16 times a weight: k_major False -> a @ w.T with w (N, K) (F.linear); True -> a @ w with w (K, N) (the
+    input gradient of F.linear) -- csrc/ss2d_tokgemm.hip.  Returns (..., N) bf16, or None when dtype / layout do not
+    qualify (the caller then uses the BLAS library)."""
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not a.is_cuda or w.dim() != 2:
+        return None
+    K = a.shape[-1]
+    N = w.shape[1] if k_major else w.shape[0]
+    if (w.shape[0] if k_major else w.shape[1]) != K or K % 8 or N % 8 or not w.is_contiguous() or w.data_ptr() % 16:
+        return None
+    a2 = a.reshape(-1, K)
+    if a2.shape[0] == 0 or a2.stride(1) != 1 or a2.data_ptr() % 16:
+        return None
+    lda = a2.stride(0) if a2.shape[0] > 1 else K
+    if lda % 8 or lda < K:
+        return None
+    out = torch.empty((a2.shape[0], N), device=a.device, dtype=torch.bfloat16)
+    with torch.cuda.device(a.device):
+        rc = _lib.load().ss2d_token_gemm(_BF16, _lib.ptr(a2), _lib.ptr(w), _lib.ptr(out), a2.shape[0], N, K, lda,
+                                         w.stride(0), N, int(k_major), _stream())
+    _lib.check(rc, "ss2d_token_gemm")
+    return out.view(*a.shape[:-1], N)
+
+
+def _token_gemm_pays(tokens: int, n: int, k: int) -> bool:
+    """The own kernel walks the whole contraction in one workgroup per 128 x 96 tile: with a long contraction and too few
+    tiles to fill 256 CUs (stage 3: 1176 tokens) the library's split is faster (tools/token_gemm_bench.py)."""
+    return _OWN_TOKEN_GEMM and not (k >= 1536 and ((tokens + 127) // 128) * ((n + 95) // 96) < 256)
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T (+ b) for the Linears whose token axis dwarfs both feature axes: forward and dX stay on
-    hipBLASLt (F.linear / matmul, good shapes), dW goes to the split-token MFMA kernel, db is a column sum."""
+    """y = x W^T (+ b) for the Linears whose token axis dwarfs both feature axes: bf16 forward and dX on the token-major
+    MFMA kernel (ss2d_token_gemm; hipBLASLt for fp32, with a bias, and where _token_gemm_pays says no), dW on the
+    split-token MFMA kernel, db a column sum."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -329,6 +365,10 @@ class _Linear(torch.autograd.Function):
             w, b = weight, bias
         ctx.save_for_backward(x, w)
         ctx.w_dtype, ctx.b_dtype = weight.dtype, None if bias is None else bias.dtype
+        own = b is None and _token_gemm_pays(x.numel() // x.shape[-1], w.shape[0], w.shape[1])
+        y = token_gemm(x, w, False) if own else None                                   # bf16, bias-free: own MFMA kernel
+        if y is not None:
+            return y
         with torch.autocast("cuda", enabled=False):
             return torch.nn.functional.linear(x, w, b)
 
@@ -336,7 +376,11 @@ class _Linear(torch.autograd.Function):
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         g = g.to(x.dtype)
-        dx = torch.matmul(g, w) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = token_gemm(g, w, True) if _token_gemm_pays(g.numel() // g.shape[-1], w.shape[1], w.shape[0]) else None
+            if dx is None:
+                dx = torch.matmul(g, w)
         dw = linear_wgrad(g, x).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
         db = None
         if ctx.b_dtype is not None and ctx.needs_input_grad[2]:

@@ -493,6 +493,48 @@ def test_chan_gemm_mfma(B, G, M, K, L):
     assert chan_gemm(W.cuda().float(), Xd.float()) is None              # fp32: library
 
 
+@pytest.mark.parametrize("T,N,K", [(3136, 384, 96), (3136, 96, 192), (777, 192, 384), (130, 1536, 768), (49, 768, 1536), (1, 8, 8),
+                                   (1000, 104, 40), (257, 96, 264)])
+@pytest.mark.parametrize("k_major", [False, True])
+def test_token_gemm_mfma(T, N, K, k_major):
+    """The token-major Linear forward (a @ w.T) and input gradient (a @ w) of in_proj / out_proj / merge / expand in bf16
+    against an fp64 product of the same bf16 values: whole and ragged token tiles, column tiles and k chunks, both chunk
+    sizes, a row range of a wider buffer as the token operand."""
+    from mamba_unet_amd.ss2d_ops import token_gemm
+    gen = torch.Generator().manual_seed(T + 3 * N + 5 * K + int(k_major))
+    a_wide = torch.randn(T, K + 16, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(*((K, N) if k_major else (N, K)), generator=gen) * 0.2).to(torch.bfloat16)
+    a = a_wide.cuda()[:, 8:8 + K]
+    guard = torch.full((T + 2, N), 7.0, dtype=torch.bfloat16, device="cuda")            # nothing may be written around the result
+    got = token_gemm(a, w.cuda(), k_major)
+    assert got is not None and got.shape == (T, N) and got.dtype == torch.bfloat16
+    want = a_wide[:, 8:8 + K].double() @ (w.double() if k_major else w.double().t())
+    assert rel_l2(got.float().cpu(), want) < 4e-3                     # bf16 rounding of the result only
+    assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    assert bool((guard == 7.0).all())
+    assert token_gemm(a.float(), w.cuda().float(), k_major) is None     # fp32: library
+    a3 = a.reshape(1, T, K)                                             # leading batch axes are flattened
+    got3 = token_gemm(a3, w.cuda(), k_major)
+    assert got3.shape == (1, T, N) and torch.equal(got3[0], got)
+
+
+def test_linear_function_bf16():
+    """ss2d_ops.linear (forward on the token GEMM, dX on its k-major mode, dW on the split-token kernel) against fp64
+    autograd of the same bf16 values, and bit-identical output with the library switch."""
+    from mamba_unet_amd import ss2d_ops
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 28, 28, 192, generator=gen).to(torch.bfloat16)
+    w = (torch.randn(768, 192, generator=gen) * 0.1).to(torch.bfloat16)
+    g = torch.randn(2, 28, 28, 768, generator=gen).to(torch.bfloat16)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    (xr @ wr.t()).backward(g.double())
+    xd, wd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    y = ss2d_ops._Linear.apply(xd, wd, None)
+    y.backward(g.cuda())
+    assert rel_l2(y.detach().float().cpu(), (x.double() @ w.double().t())) < 4e-3
+    assert rel_l2(xd.grad.float().cpu(), xr.grad) < 4e-3 and rel_l2(wd.grad.float().cpu(), wr.grad) < 4e-3
+
+
 @pytest.mark.parametrize("dtype,L", [(torch.float32, 784), (torch.bfloat16, 784), (torch.bfloat16, 196), (torch.bfloat16, 49)])
 def test_x_proj_function(dtype, L):
     """x_proj forward, dX and dW (MFMA kernels in bf16 where the layout allows, library otherwise) against fp64 autograd of
