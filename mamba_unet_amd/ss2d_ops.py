@@ -328,8 +328,8 @@ def token_gemm(a: torch.Tensor, w: torch.Tensor, k_major: bool):
         return None
     K = a.shape[-1]
     N = w.shape[1] if k_major else w.shape[0]
-    if (w.shape[0] if k_major else w.shape[1]) != K or K % 8 or N % 8 or not w.is_contiguous() or w.data_ptr() % 16:
-        return None
+    if (w.shape[0] if k_major else w.shape[1]) != K or K % 8 or N % 8 or w.stride(1) != 1 or w.stride(0) % 8 or w.data_ptr() % 16:
+        return None                                                   # a column range of a wider weight is fine (_ConcatLinear)
     a2 = a.reshape(-1, K)
     if a2.shape[0] == 0 or a2.stride(1) != 1 or a2.data_ptr() % 16:
         return None
@@ -342,6 +342,18 @@ def token_gemm(a: torch.Tensor, w: torch.Tensor, k_major: bool):
                                          w.stride(0), N, int(k_major), _stream())
     _lib.check(rc, "ss2d_token_gemm")
     return out.view(*a.shape[:-1], N)
+
+
+def _own_wgrad_pays(rows: int, m: int, n: int, dtype) -> bool:
+    """Split-token MFMA weight gradient or the library's g^T x: the own kernel wins wherever the token axis is long against
+    the output (stages 0 / 1, fp32 and bf16) and, in bf16, down to ~2000 tokens (stage 2: 21-28 us against 37; at the 1176
+    tokens of stage 3 they tie) -- tools/wgrad_shapes_bench.py."""
+    return rows >= 32 * min(m, n) or (dtype == torch.bfloat16 and rows >= 2048 and m % 8 == 0 and n % 8 == 0)
+
+
+def _lib_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    g2 = g.reshape(-1, g.shape[-1])
+    return g2.t() @ x.reshape(g2.shape[0], -1)
 
 
 def _token_gemm_pays(tokens: int, n: int, k: int) -> bool:
@@ -381,7 +393,10 @@ class _Linear(torch.autograd.Function):
             dx = token_gemm(g, w, True) if _token_gemm_pays(g.numel() // g.shape[-1], w.shape[1], w.shape[0]) else None
             if dx is None:
                 dx = torch.matmul(g, w)
-        dw = linear_wgrad(g, x).to(ctx.w_dtype) if ctx.needs_input_grad[1] else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            own = _own_wgrad_pays(g.numel() // g.shape[-1], g.shape[-1], x.shape[-1], g.dtype)
+            dw = (linear_wgrad(g, x) if own else _lib_wgrad(g, x)).to(ctx.w_dtype)
         db = None
         if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
             db = colsum(g).to(ctx.b_dtype)
@@ -416,16 +431,17 @@ class _ConcatLinear(torch.autograd.Function):
         x, skip, w = ctx.saved_tensors
         g = g.to(x.dtype)
         C1 = x.shape[-1]
-        dx = torch.matmul(g, w[:, :C1]) if ctx.needs_input_grad[0] else None
-        dskip = torch.matmul(g, w[:, C1:]) if ctx.needs_input_grad[1] else None
+        rows, M = g.numel() // g.shape[-1], g.shape[-1]
+
+        def dinput(wpart):                 # g @ W[:, part]: the k-major token GEMM reads the column range in place
+            d = token_gemm(g, wpart, True) if _token_gemm_pays(rows, wpart.shape[1], M) else None
+            return torch.matmul(g, wpart) if d is None else d
+        dx = dinput(w[:, :C1]) if ctx.needs_input_grad[0] else None
+        dskip = dinput(w[:, C1:]) if ctx.needs_input_grad[1] else None
         dw = None
         if ctx.needs_input_grad[2]:
-            rows, M = g.numel() // g.shape[-1], g.shape[-1]
-            if rows >= 32 * min(M, C1):
-                dw = torch.cat([linear_wgrad(g, x), linear_wgrad(g, skip)], dim=1).to(ctx.w_dtype)
-            else:
-                g2 = g.reshape(-1, M)
-                dw = torch.cat([g2.t() @ x.reshape(rows, -1), g2.t() @ skip.reshape(rows, -1)], dim=1).to(ctx.w_dtype)
+            wg = linear_wgrad if _own_wgrad_pays(rows, M, C1, g.dtype) else _lib_wgrad
+            dw = torch.cat([wg(g, x), wg(g, skip)], dim=1).to(ctx.w_dtype)
         db = colsum(g).to(ctx.b_dtype) if (ctx.b_dtype is not None and ctx.needs_input_grad[3]) else None
         return dx, dskip, dw, db
 
@@ -438,10 +454,10 @@ def concat_linear(module: torch.nn.Module, x: torch.Tensor, skip: torch.Tensor) 
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-    """F.linear(x, weight, bias) with the weight gradient on the MFMA split-token kernel when the token axis is
-    long (>= 32x the smaller feature axis: stages 0 and 1 of MambaUNet); plain F.linear otherwise."""
+    """F.linear(x, weight, bias) through _Linear on the GPU: every product goes to the own MFMA kernel or to the BLAS library
+    by shape (_token_gemm_pays, _own_wgrad_pays); plain F.linear for a handful of rows, on the CPU, and with the A/B switch."""
     rows = x.numel() // x.shape[-1]
-    if x.is_cuda and rows >= 32 * min(weight.shape) and not _os.environ.get("SS2D_NO_WGRAD"):   # env: A/B switch
+    if x.is_cuda and rows >= 1024 and not _os.environ.get("SS2D_NO_WGRAD"):   # env: A/B switch
         return _Linear.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
 
