@@ -99,6 +99,37 @@ def ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+class _Here:
+    """The no-op context of `on_device` (one shared instance)."""
+
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_HERE = _Here()
+
+
+def on_device(dev):
+    """`with on_device(t.device):` around a launch -- `torch.cuda.device(dev)` only when dev is not already the current
+    device.  The context manager costs ~8 us of host time per use and a training step launches ~600 kernels of this
+    library: the host, not the GPU, set the pace of the eager step on a box with slow cores."""
+    import torch
+    idx = dev.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _HERE
+    return torch.cuda.device(dev)
+
+
+def stream():
+    """Raw handle of torch's current stream on the current device (the same value as
+    torch.cuda.current_stream().cuda_stream without building a Stream object: 0.3 us instead of 9)."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+
+
 _ARENA = {}                 # device -> [zero-filled fp32 chunk, floats handed out, capture epoch]
 _ARENA_EPOCH = [0, False]   # bumped whenever the stream's capture state changes between two requests
 _ARENA_FLOATS = 1 << 20     # 4 MB per chunk

@@ -16,8 +16,7 @@ from .ss2d_ops import chan_gemm, chan_wgrad
 _F32, _BF16 = 0, 1          # include/ss2d.h: SS2D_DTYPE_F32 / SS2D_DTYPE_BF16
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_stream = _lib.stream
 
 
 def _bwd_buffers(lib, dev, batch, dim, L, dstate, G, has_z, shA, shD, shbias, shB, shC):
@@ -91,7 +90,7 @@ class SelectiveScanFn(torch.autograd.Function):
         ckpt = None
         if needs_grad:
             ckpt = torch.empty((batch, dim, lib.ss2d_scan_num_chunks(L), dstate), device=u_.device, dtype=torch.float32)
-        with torch.cuda.device(u_.device):
+        with _lib.on_device(u_.device):
             rc = lib.ss2d_selective_scan_fwd(code, _lib.ptr(u_), _lib.ptr(delta_), _lib.ptr(A_), _lib.ptr(B_),
                                              _lib.ptr(C_), _lib.ptr(D_), _lib.ptr(z_), _lib.ptr(bias_),
                                              _lib.ptr(out), _lib.ptr(last), _lib.ptr(ckpt), batch, dim, L, dstate, G,
@@ -121,7 +120,7 @@ class SelectiveScanFn(torch.autograd.Function):
         dA, dD, dbias, dB, dC, ws, wsb = _bwd_buffers(lib, u.device, batch, dim, L, dstate, G, z is not None,
                                                        sh(A), sh(D), sh(bias), sh(B), sh(C))
         dz = torch.empty_like(z) if z is not None else None
-        with torch.cuda.device(u.device):
+        with _lib.on_device(u.device):
             rc = lib.ss2d_selective_scan_dir_bwd_ws(ctx.code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(B), _lib.ptr(C),
                                                     _lib.ptr(D), _lib.ptr(z), _lib.ptr(bias), _lib.ptr(dout), _lib.ptr(ckpt),
                                                     _lib.ptr(du), _lib.ptr(ddelta), _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC),
@@ -181,7 +180,7 @@ class ScanMergeFn(torch.autograd.Function):
         ckpt = torch.empty((batch, dim, lib.ss2d_scan_num_chunks(L), N), device=u_.device, dtype=torch.float32) if needs_grad else None
         Dch = dim // 4
         y = torch.empty((batch, H, W, Dch), device=u_.device, dtype=io)
-        with torch.cuda.device(u_.device):
+        with _lib.on_device(u_.device):
             rc = lib.ss2d_selective_scan_dir_fwd(code, _lib.ptr(u_), _lib.ptr(delta_), _lib.ptr(A_), _lib.ptr(B_), _lib.ptr(C_),
                                                  _lib.ptr(D_), None, _lib.ptr(bias_), _lib.ptr(out), None, _lib.ptr(ckpt),
                                                  batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, bcs, _stream())
@@ -209,7 +208,7 @@ class ScanMergeFn(torch.autograd.Function):
         du, ddelta = torch.empty_like(delta), torch.empty_like(delta)
         sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
         dA, dD, dbias, dB, dC, ws, wsb = _bwd_buffers(lib, g.device, batch, dim, L, N, 4, False, sh(A), sh(D), sh(bias), sh(Bm), sh(Cm))
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_scatter")
             rc = lib.ss2d_selective_scan_dir_bwd_ws(code, _lib.ptr(u), _lib.ptr(delta), _lib.ptr(A), _lib.ptr(Bm), _lib.ptr(Cm),
@@ -272,7 +271,7 @@ class ScanCoreFn(torch.autograd.Function):
         ckpt = torch.empty((batch, dim, lib.ss2d_scan_num_chunks(L), N), device=dev, dtype=torch.float32) if needs_grad else None
         y = torch.empty((batch, H, W, Dch), device=dev, dtype=io)
         fused_delta = ScanCoreFn.FUSE_DELTA and R in (6, 12) and L % 4 == 0 and N == 16
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             if fused_delta:
                 # delta = dt_w . dts is computed inside the scan kernels (forward and backward): never materialised
                 delta = None
@@ -331,7 +330,7 @@ class ScanCoreFn(torch.autograd.Function):
         else:
             B_, C_, bcs = xd[:, :, R:R + N].contiguous(), xd[:, :, R + N:].contiguous(), N * L
         d_xdbl = torch.empty_like(xd)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
             _lib.check(rc, "ss2d_dirs_scatter")
             if ctx.fused_delta:

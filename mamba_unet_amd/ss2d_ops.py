@@ -20,8 +20,7 @@ def _io(t):
     return (torch.bfloat16, _BF16) if t.dtype == torch.bfloat16 else (torch.float32, _F32)
 
 
-def _stream():
-    return torch.cuda.current_stream().cuda_stream
+_stream = _lib.stream
 
 
 def _need_gpu(t, what):
@@ -38,7 +37,7 @@ class _CrossScan(torch.autograd.Function):
         io, code = _io(x)
         xf = x.to(io).contiguous()
         xs = torch.empty((B, 4, D, H * W), device=x.device, dtype=io)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.load().ss2d_cross_scan_fwd(code, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, _stream())
         _lib.check(rc, "ss2d_cross_scan_fwd")
         ctx.shape, ctx.in_dtype = (B, D, H, W), in_dtype
@@ -50,7 +49,7 @@ class _CrossScan(torch.autograd.Function):
         io, code = _io(dxs)
         g = dxs.to(io).contiguous()
         dx = torch.empty((B, D, H, W), device=g.device, dtype=io)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             rc = _lib.load().ss2d_cross_scan_bwd(code, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, _stream())
         _lib.check(rc, "ss2d_cross_scan_bwd")
         return dx.to(ctx.in_dtype)
@@ -68,7 +67,7 @@ class _CrossMerge(torch.autograd.Function):
         yf = ys.to(io).contiguous()
         shape = (B, H, W, D) if channel_last else (B, D, L)
         y = torch.empty(shape, device=ys.device, dtype=io)
-        with torch.cuda.device(ys.device):
+        with _lib.on_device(ys.device):
             rc = _lib.load().ss2d_cross_merge_fwd(code, _lib.ptr(yf), _lib.ptr(y), B, D, H, W, int(channel_last), _stream())
         _lib.check(rc, "ss2d_cross_merge_fwd")
         ctx.dims, ctx.in_dtype = (B, D, H, W, int(channel_last)), in_dtype
@@ -80,7 +79,7 @@ class _CrossMerge(torch.autograd.Function):
         io, code = _io(dy)
         g = dy.to(io).contiguous()
         dys = torch.empty((B, 4, D, H * W), device=g.device, dtype=io)
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             rc = _lib.load().ss2d_cross_merge_bwd(code, _lib.ptr(g), _lib.ptr(dys), B, D, H, W, cl, _stream())
         _lib.check(rc, "ss2d_cross_merge_bwd")
         return dys.to(ctx.in_dtype), None, None, None
@@ -146,7 +145,7 @@ class _DwConvSiLU(torch.autograd.Function):
         wf = weight.float().contiguous()
         bf = None if bias is None else bias.float().contiguous()
         y = torch.empty((B, D, H, W), device=x.device, dtype=io)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.load().ss2d_dwconv3x3_silu_fwd(code, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(y),
                                                      B, D, H, W, int(channel_last_in), ldx, _stream())
         _lib.check(rc, "ss2d_dwconv3x3_silu_fwd")
@@ -165,7 +164,7 @@ class _DwConvSiLU(torch.autograd.Function):
         else:
             dx, lddx = torch.empty((B, H, W, D) if cl else (B, D, H, W), device=g.device, dtype=xf.dtype), D
         dw, db = _lib.zeros_group(g.device, tuple(wf.shape), None if bf is None else tuple(bf.shape))
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             rc = _lib.load().ss2d_dwconv3x3_silu_bwd(code, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(g),
                                                      _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), B, D, H, W, cl, ldx, lddx,
                                                      _stream())
@@ -204,7 +203,7 @@ def linear_wgrad(grad_out: torch.Tensor, inp: torch.Tensor) -> torch.Tensor:
     if g2.shape[0] != x2.shape[0]:
         raise ValueError(f"linear_wgrad: {tuple(grad_out.shape)} and {tuple(inp.shape)} disagree on the token axes")
     dw = _lib.zeros(grad_out.device, (M, N))
-    with torch.cuda.device(grad_out.device):
+    with _lib.on_device(grad_out.device):
         rc = _lib.load().ss2d_linear_wgrad(code, _lib.ptr(g2), _lib.ptr(x2), _lib.ptr(dw), g2.shape[0], M, N,
                                            g2.stride(0), x2.stride(0), N, _stream())
     _lib.check(rc, "ss2d_linear_wgrad")
@@ -227,7 +226,7 @@ def chan_wgrad(P: torch.Tensor, Q: torch.Tensor) -> torch.Tensor:
     code = _BF16 if P.dtype == torch.bfloat16 else _F32
     out = _lib.zeros(P.device, (G, M, N))
     wide, narrow, soi, soj, Mb, Ns = (P, Q, N, 1, M, N) if M >= N else (Q, P, 1, N, N, M)
-    with torch.cuda.device(P.device):
+    with _lib.on_device(P.device):
         rc = _lib.load().ss2d_chan_wgrad(code, _lib.ptr(wide), _lib.ptr(narrow), _lib.ptr(out), B, G, Mb, Ns, L, wide.stride(0),
                                          wide.stride(1), narrow.stride(0), narrow.stride(1), M * N, soi, soj, _stream())
     _lib.check(rc, "ss2d_chan_wgrad")
@@ -249,7 +248,7 @@ def chan_gemm(W: torch.Tensor, X: torch.Tensor):
     Wp = W.to(torch.bfloat16)
     Wp = torch.nn.functional.pad(Wp, (0, ldw - K)) if ldw != K else Wp.contiguous()
     Y = torch.empty((B, G, M, L), device=X.device, dtype=torch.bfloat16)
-    with torch.cuda.device(X.device):
+    with _lib.on_device(X.device):
         rc = _lib.load().ss2d_chan_gemm(_BF16, _lib.ptr(Wp), _lib.ptr(X), _lib.ptr(Y), B, G, M, K, ldw, L, M * ldw, X.stride(0),
                                         X.stride(1), G * M * L, M * L, _stream())
     _lib.check(rc, "ss2d_chan_gemm")
@@ -311,7 +310,7 @@ def colsum(g: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     out = torch.empty(M, device=g.device, dtype=torch.float32)
     ws = torch.empty(int(lib.ss2d_colsum_workspace_floats(M)), device=g.device, dtype=torch.float32)
-    with torch.cuda.device(g.device):
+    with _lib.on_device(g.device):
         rc = lib.ss2d_colsum(code, _lib.ptr(g2), _lib.ptr(out), _lib.ptr(ws), g2.shape[0], M, g2.stride(0), _stream())
     _lib.check(rc, "ss2d_colsum")
     return out
@@ -337,7 +336,7 @@ def token_gemm(a: torch.Tensor, w: torch.Tensor, k_major: bool):
     if lda % 8 or lda < K:
         return None
     out = torch.empty((a2.shape[0], N), device=a.device, dtype=torch.bfloat16)
-    with torch.cuda.device(a.device):
+    with _lib.on_device(a.device):
         rc = _lib.load().ss2d_token_gemm(_BF16, _lib.ptr(a2), _lib.ptr(w), _lib.ptr(out), a2.shape[0], N, K, lda,
                                          w.stride(0), N, int(k_major), _stream())
     _lib.check(rc, "ss2d_token_gemm")
@@ -499,7 +498,7 @@ class _OutNormGate(torch.autograd.Function):
         out = torch.empty((rows, D), device=y.device, dtype=io)
         mean = torch.empty(rows, device=y.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        with torch.cuda.device(y.device):
+        with _lib.on_device(y.device):
             rc = _lib.load().ss2d_outnorm_gate_fwd(code, _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32), _lib.ptr(b32),
                                                    _lib.ptr(out), _lib.ptr(mean), _lib.ptr(rstd), rows, D, ldz,
                                                    float(eps), _stream())
@@ -522,7 +521,7 @@ class _OutNormGate(torch.autograd.Function):
         else:
             dz, lddz = torch.empty((rows, D), device=g.device, dtype=y2.dtype), D
         dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(b32.shape))
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             rc = _lib.load().ss2d_outnorm_gate_bwd(code, _lib.ptr(g), _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32),
                                                    _lib.ptr(b32), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dy),
                                                    _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), rows, D, ldz, lddz, _stream())
@@ -570,7 +569,7 @@ class _LayerNorm(torch.autograd.Function):
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
         lib = _lib.load()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             if ps < 0:
                 rc = lib.ss2d_layernorm_merge_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(out),
                                                   _lib.ptr(mean), _lib.ptr(rstd), B, H, W, C, float(eps), _stream())
@@ -594,7 +593,7 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x2)
         dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(g32.shape))
         lib = _lib.load()
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             if ps < 0:
                 B, H, W, C = xshape
                 rc = lib.ss2d_layernorm_merge_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
@@ -689,7 +688,7 @@ class _DirsScatter2(torch.autograd.Function):
         io, code = _io(x)
         xf = x.to(io).contiguous()
         xs = torch.empty((B, 2, D, H * W), device=x.device, dtype=io)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.load().ss2d_dirs_scatter(code, 2, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, 0, _stream())
         _lib.check(rc, "ss2d_dirs_scatter")
         ctx.shape, ctx.in_dtype = (B, D, H, W), x.dtype
@@ -704,7 +703,7 @@ class _DirsScatter2(torch.autograd.Function):
         du = None
         if ctx.holder is not None:
             du, ctx.holder.du = ctx.holder.du, None
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             if du is not None and du.dtype == io and tuple(du.shape) == (B, 4 * D, H * W) and du.is_contiguous():
                 rc = _lib.load().ss2d_dirs_gather6(code, _lib.ptr(du), _lib.ptr(g), _lib.ptr(dx), B, D, H, W, _stream())
                 du = None
@@ -713,7 +712,7 @@ class _DirsScatter2(torch.autograd.Function):
         _lib.check(rc, "ss2d_dirs_gather")
         if du is not None:      # a du this node could not fold in (dtype / shape): gather it the plain way and add
             dx2 = torch.empty_like(dx)
-            with torch.cuda.device(g.device):
+            with _lib.on_device(g.device):
                 rc = _lib.load().ss2d_dirs_gather(code, 1, _lib.ptr(du.to(io).contiguous()), _lib.ptr(dx2), B, D, H, W, 0, _stream())
             _lib.check(rc, "ss2d_dirs_gather")
             dx = dx + dx2
@@ -740,7 +739,7 @@ class _DtProj(torch.autograd.Function):
             xs = xs.contiguous()
         w32 = weight.float().contiguous()
         out = torch.empty((B, G, D, L), device=x.device, dtype=io)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.load().ss2d_dt_proj_fwd(code, _lib.ptr(xs), _lib.ptr(w32), _lib.ptr(out), B, G, D, R, L,
                                               xs.stride(1), _stream())
         _lib.check(rc, "ss2d_dt_proj_fwd")
@@ -784,7 +783,7 @@ class _ScanParams(torch.autograd.Function):
         D = torch.empty((K * Dm,), device=dev, dtype=torch.float32)
         bias = torch.empty((K * Dm,), device=dev, dtype=torch.float32)
         w = torch.empty((K, Dm, R), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.load().ss2d_scan_params_fwd(*[_lib.ptr(t) for t in src], _lib.ptr(A), _lib.ptr(D), _lib.ptr(bias),
                                                   _lib.ptr(w), K, Dm, N, R, int(regroup), _stream())
         _lib.check(rc, "ss2d_scan_params_fwd")
@@ -802,7 +801,7 @@ class _ScanParams(torch.autograd.Function):
         dDs = torch.empty((K * Dm,), device=dev, dtype=torch.float32)
         ddt_bias = torch.empty(bias_shape, device=dev, dtype=torch.float32)
         ddt_w = torch.empty((K, Dm, R), device=dev, dtype=torch.float32)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             rc = _lib.load().ss2d_scan_params_bwd(_lib.ptr(A), *[_lib.ptr(t) for t in g], _lib.ptr(dA_logs), _lib.ptr(dDs),
                                                   _lib.ptr(ddt_bias), _lib.ptr(ddt_w), K, Dm, N, R, regroup, _stream())
         _lib.check(rc, "ss2d_scan_params_bwd")
@@ -837,7 +836,7 @@ class _LNHead(torch.autograd.Function):
         logits = torch.empty((B, nc, H * ps, W * ps), device=x.device, dtype=odt)
         mean = torch.empty(rows, device=x.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             rc = _lib.load().ss2d_ln_head_fwd(code, ocode, _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(w32),
                                               _lib.ptr(logits), _lib.ptr(mean), _lib.ptr(rstd), B, H, W, ps, D, nc,
                                               float(eps), _stream())
@@ -856,7 +855,7 @@ class _LNHead(torch.autograd.Function):
         g = g if g.is_contiguous() else g.contiguous()
         dx = torch.empty_like(x2)
         dg, db, dw = _lib.zeros_group(g.device, (D,), (D,), (nc, D))
-        with torch.cuda.device(g.device):
+        with _lib.on_device(g.device):
             rc = _lib.load().ss2d_ln_head_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(w32),
                                               _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db),
                                               _lib.ptr(dw), B, H, W, ps, D, nc, _stream())
@@ -901,7 +900,7 @@ class _SegLossStats(torch.autograd.Function):
         lib = _lib.load()
         stats = torch.empty(3 * C + 1, device=lg.device, dtype=torch.float32)
         ws = torch.empty(int(lib.ss2d_seg_loss_workspace_floats(C)), device=lg.device, dtype=torch.float32)
-        with torch.cuda.device(lg.device):
+        with _lib.on_device(lg.device):
             rc = lib.ss2d_seg_loss_stats(code, _lib.ptr(lg), _lib.ptr(lb), lb.element_size(), _lib.ptr(stats), _lib.ptr(ws),
                                          B, C, HW, _stream())
         _lib.check(rc, "ss2d_seg_loss_stats")
@@ -915,7 +914,7 @@ class _SegLossStats(torch.autograd.Function):
         code, B, C, HW, in_dtype = ctx.meta
         g32 = g.float().contiguous()
         dl = torch.empty_like(lg)
-        with torch.cuda.device(lg.device):
+        with _lib.on_device(lg.device):
             rc = _lib.load().ss2d_seg_loss_bwd(code, _lib.ptr(lg), _lib.ptr(lb), lb.element_size(), _lib.ptr(g32), _lib.ptr(dl),
                                                B, C, HW, _stream())
         _lib.check(rc, "ss2d_seg_loss_bwd")
