@@ -168,6 +168,17 @@ int ss2d_dirs_gather(int dtype, int layout, const void *ys, void *y, int B, int 
  * (SS2D_DIRS_MIRROR_FREE_2) in one pass: autograd's sum of the two gradients that reach x in SS2D's backward -- du of the
  * selective scan (mamba_sys.py:436-442) through CrossScan (:403-404) and the input gradient of x_proj (:407). */
 int ss2d_dirs_gather6(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, void *stream);
+/* The same three with a row pitch: the rows of the direction-side tensor (H*W positions each) lie `row_pitch` >= H*W
+ * elements apart; the image side is unchanged.  For a caller whose H*W is odd (the 7 x 7 stage of a 224 x 224 input,
+ * mamba_sys.py:403 with L = 49): it pads the rows to a multiple of 8, zero-fills the pad once, and runs x_proj, dt_proj and
+ * the scan (:407-442) on the padded length with their aligned fast paths -- u = 0 in the pad keeps the state of a reversed
+ * scan at zero until the first real position, and a forward scan reaches the pad after the last one. */
+int ss2d_dirs_scatter_ld(int dtype, int layout, const void *x, void *xs, int B, int D, int H, int W, int x_channel_last,
+                         long long row_pitch, void *stream);
+int ss2d_dirs_gather_ld(int dtype, int layout, const void *ys, void *y, int B, int D, int H, int W, int y_channel_last,
+                        long long row_pitch, void *stream);
+int ss2d_dirs_gather6_ld(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, long long row_pitch,
+                         void *stream);
 
 /* Depthwise 3x3 conv (pad 1, bias) + SiLU (mamba_sys.py:299-308, :558-559).
  *   x: channel_last_in ? (B, H, W, ldx) with the D channels first (ldx >= D lets it read the x half of

@@ -31,6 +31,7 @@ struct CrossParams {
     // second slot of each pair is stored reversed (the reference's layout: rmB 2, cmA 1, cmB 3, revB 1).  The
     // mirror-free layouts used with ss2d_selective_scan_dir_*: 4 slots (0,1 | 2,3), revB 0, or 2 slots (0 | 1).
     int nslots, rmB, cmA, cmB, revB;
+    long long lrow;    // row pitch (elements) of the direction-side tensor: H*W, or more when the caller pads its rows
 };
 
 template <typename T>
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
     int b, d0, h0, w0;
     tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
-    const size_t L = (size_t)H * W;
+    const size_t L = (size_t)H * W, LR = (size_t)p.lrow;   // positions of a row; row pitch of the direction side (>= L)
     constexpr int NIT = T::N / 256;
 #pragma unroll 1
     for (int it0 = 0; it0 < NIT; it0 += UB) {
@@ -98,9 +99,9 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const float v = s[d * T::SD + h * T::SW + w];
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            IO *o0 = out + (((size_t)b * p.nslots + 0) * D + d0 + d) * L;
+            IO *o0 = out + (((size_t)b * p.nslots + 0) * D + d0 + d) * LR;
             st1(o0 + pp, v);
-            if (p.nslots == 4) st1(out + (((size_t)b * 4 + p.rmB) * D + d0 + d) * L + (p.revB ? L - 1 - pp : pp), v);
+            if (p.nslots == 4) st1(out + (((size_t)b * 4 + p.rmB) * D + d0 + d) * LR + (p.revB ? L - 1 - pp : pp), v);
         }
     }
     // column-major directions 1 and 3: h on the fast lanes
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(256) void cross_scan_kernel(const CrossParams p) {
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
             const float v = s[d * T::SD + h * T::SW + w];
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            IO *o1 = out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L;
+            IO *o1 = out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * LR;
             st1(o1 + q, v);
-            if (p.nslots == 4) st1(out + (((size_t)b * 4 + p.cmB) * D + d0 + d) * L + (p.revB ? L - 1 - q : q), v);
+            if (p.nslots == 4) st1(out + (((size_t)b * 4 + p.cmB) * D + d0 + d) * LR + (p.revB ? L - 1 - q : q), v);
         }
     }
 }
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
     int b, d0, h0, w0;
     tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
-    const size_t L = (size_t)H * W;
+    const size_t L = (size_t)H * W, LR = (size_t)p.lrow;   // positions of a row; row pitch of the direction side (>= L)
     constexpr int NIT = T::N / 256;
     const bool four = p.nslots == 4;
     const int sB = four ? 4 : p.nslots;
@@ -140,10 +141,10 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
             dec_row<T, 1>(tid + (it0 + u) * 256, d, h, w);
             const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - 1);
             const size_t pp = (size_t)hc * W + wc;
-            v[u] = ld1(in + (((size_t)b * p.nslots + 0) * D + dc) * L + pp);
+            v[u] = ld1(in + (((size_t)b * p.nslots + 0) * D + dc) * LR + pp);
             // with two slots rmB is 0: the same element again, not added
-            v2[u] = ld1(in + (((size_t)b * sB + p.rmB) * D + dc) * L + (p.revB ? L - 1 - pp : pp));
-            if (EXTRA) v4[u] = ld1(in2 + (((size_t)b * 2 + 0) * D + dc) * L + pp);
+            v2[u] = ld1(in + (((size_t)b * sB + p.rmB) * D + dc) * LR + (p.revB ? L - 1 - pp : pp));
+            if (EXTRA) v4[u] = ld1(in2 + (((size_t)b * 2 + 0) * D + dc) * LR + pp);
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
@@ -163,9 +164,9 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
             dec_col<T, 1>(tid + (it0 + u) * 256, d, h, w);
             const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - 1);
             const size_t q = (size_t)wc * H + hc;
-            v1[u] = ld1(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * L + q);
-            v3[u] = ld1(in + (((size_t)b * sB + p.cmB) * D + dc) * L + (p.revB ? L - 1 - q : q));
-            if (EXTRA) v5[u] = ld1(in2 + (((size_t)b * 2 + 1) * D + dc) * L + q);
+            v1[u] = ld1(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * LR + q);
+            v3[u] = ld1(in + (((size_t)b * sB + p.cmB) * D + dc) * LR + (p.revB ? L - 1 - q : q));
+            if (EXTRA) v5[u] = ld1(in2 + (((size_t)b * 2 + 1) * D + dc) * LR + q);
         }
         // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
 #pragma unroll
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
     int b, d0, h0, w0;
     tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
-    const size_t L = (size_t)H * W;
+    const size_t L = (size_t)H * W, LR = (size_t)p.lrow;   // positions of a row; row pitch of the direction side (>= L)
     constexpr int NIT = T::N / 4 / 256;
     {
         f4 v[NIT];
@@ -232,9 +233,9 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = s[d * T::SD + h * T::SW + w + e];
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            st4(out + (((size_t)b * p.nslots + 0) * D + d0 + d) * L + pp, v);
+            st4(out + (((size_t)b * p.nslots + 0) * D + d0 + d) * LR + pp, v);
             if (p.nslots == 4) {
-                IO *o2 = out + (((size_t)b * 4 + p.rmB) * D + d0 + d) * L;
+                IO *o2 = out + (((size_t)b * 4 + p.rmB) * D + d0 + d) * LR;
                 if (p.revB) st4(o2 + (L - 4 - pp), rev4(v)); else st4(o2 + pp, v);
             }
         }
@@ -247,9 +248,9 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = s[d * T::SD + (h + e) * T::SW + w];
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            st4(out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * L + q, v);
+            st4(out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * LR + q, v);
             if (p.nslots == 4) {
-                IO *o3 = out + (((size_t)b * 4 + p.cmB) * D + d0 + d) * L;
+                IO *o3 = out + (((size_t)b * 4 + p.cmB) * D + d0 + d) * LR;
                 if (p.revB) st4(o3 + (L - 4 - q), rev4(v)); else st4(o3 + q, v);
             }
         }
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
     int b, d0, h0, w0;
     tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
-    const size_t L = (size_t)H * W;
+    const size_t L = (size_t)H * W, LR = (size_t)p.lrow;   // positions of a row; row pitch of the direction side (>= L)
     constexpr int NIT = T::N / 4 / 256;
     const bool four = p.nslots == 4;
     const int sB = four ? 4 : p.nslots;
@@ -277,10 +278,10 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
             dec_row<T, 4>(tid + it * 256, d, h, w);
             const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - 4);
             const size_t pp = (size_t)hc * W + wc;
-            v[it] = ld4(in + (((size_t)b * p.nslots + 0) * D + dc) * L + pp);
-            const IO *i2 = in + (((size_t)b * sB + p.rmB) * D + dc) * L;
+            v[it] = ld4(in + (((size_t)b * p.nslots + 0) * D + dc) * LR + pp);
+            const IO *i2 = in + (((size_t)b * sB + p.rmB) * D + dc) * LR;
             v2[it] = ld4(i2 + (p.revB ? L - 4 - pp : pp));
-            if (EXTRA) v4[it] = ld4(in2 + (((size_t)b * 2 + 0) * D + dc) * L + pp);
+            if (EXTRA) v4[it] = ld4(in2 + (((size_t)b * 2 + 0) * D + dc) * LR + pp);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
@@ -303,10 +304,10 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
             dec_col<T, 4>(tid + it * 256, d, h, w);
             const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 4), wc = min(w0 + w, W - 1);
             const size_t q = (size_t)wc * H + hc;
-            v1[it] = ld4(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * L + q);
-            const IO *i3 = in + (((size_t)b * sB + p.cmB) * D + dc) * L;
+            v1[it] = ld4(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * LR + q);
+            const IO *i3 = in + (((size_t)b * sB + p.cmB) * D + dc) * LR;
             v3[it] = ld4(i3 + (p.revB ? L - 4 - q : q));
-            if (EXTRA) v5[it] = ld4(in2 + (((size_t)b * 2 + 1) * D + dc) * L + q);
+            if (EXTRA) v5[it] = ld4(in2 + (((size_t)b * 2 + 1) * D + dc) * LR + q);
         }
         // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
 #pragma unroll
@@ -355,12 +356,14 @@ void launch(bool merge, bool cl, bool vec, bool h, dim3 grid, hipStream_t s, con
 }
 
 int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, int B, int D, int H, int W, void *stream, const char *name,
-        const void *in2 = nullptr) {
+        const void *in2 = nullptr, long long lrow = 0) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("%s: unknown dtype %d", name, dtype); return -1; }
     if (!in || !out) { ss2d_set_error("%s: null pointer", name); return -2; }
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
+    if (lrow != 0 && lrow < (long long)H * W) { ss2d_set_error("%s: row pitch %lld smaller than H*W", name, lrow); return -3; }
     CrossParams p;
     p.in = in; p.in2 = in2; p.out = out; p.B = B; p.D = D; p.H = H; p.W = W;
+    p.lrow = lrow ? lrow : (long long)H * W;
     if (layout == SS2D_DIRS_REFERENCE) { p.nslots = 4; p.rmB = 2; p.cmA = 1; p.cmB = 3; p.revB = 1; }
     else if (layout == SS2D_DIRS_MIRROR_FREE_4) { p.nslots = 4; p.rmB = 1; p.cmA = 2; p.cmB = 3; p.revB = 0; }
     else if (layout == SS2D_DIRS_MIRROR_FREE_2) { p.nslots = 2; p.rmB = 0; p.cmA = 1; p.cmB = 1; p.revB = 0; }
@@ -374,7 +377,7 @@ int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, i
     const dim3 grid((unsigned)n);
     const bool h = dtype == SS2D_DTYPE_BF16;
     const uintptr_t amask = h ? 7 : 15;   // 4 elements
-    const bool vec = (H % 4 == 0) && (W % 4 == 0) && (!cl || D % 4 == 0) && ((((uintptr_t)in | (uintptr_t)in2 | (uintptr_t)out) & amask) == 0);
+    const bool vec = (H % 4 == 0) && (W % 4 == 0) && (p.lrow % 4 == 0) && (!cl || D % 4 == 0) && ((((uintptr_t)in | (uintptr_t)in2 | (uintptr_t)out) & amask) == 0);
     if (small) launch<TileSmall>(merge, cl, vec, h, grid, s, p); else launch<TileBig>(merge, cl, vec, h, grid, s, p);
     const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
@@ -408,4 +411,20 @@ extern "C" int ss2d_dirs_gather(int dtype, int layout, const void *ys, void *y, 
 extern "C" int ss2d_dirs_gather6(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, void *stream) {
     if (!ys2) { ss2d_set_error("dirs_gather6: null pointer"); return -2; }
     return run(true, false, SS2D_DIRS_MIRROR_FREE_4, dtype, ys4, y, B, D, H, W, stream, "dirs_gather6", ys2);
+}
+// The same three with a row pitch: the direction-side rows (H*W positions) lie `row_pitch` elements apart.  A caller whose
+// H*W is odd (the 7 x 7 stage) pads its rows to a multiple of 8, zero-fills the pad once, and runs x_proj / dt_proj / the
+// scan on the padded length with their aligned fast paths (zero u and zero dy in the pad leave every result unchanged).
+extern "C" int ss2d_dirs_scatter_ld(int dtype, int layout, const void *x, void *xs, int B, int D, int H, int W, int x_channel_last,
+                                    long long row_pitch, void *stream) {
+    return run(false, x_channel_last != 0, layout, dtype, x, xs, B, D, H, W, stream, "dirs_scatter_ld", nullptr, row_pitch);
+}
+extern "C" int ss2d_dirs_gather_ld(int dtype, int layout, const void *ys, void *y, int B, int D, int H, int W, int y_channel_last,
+                                   long long row_pitch, void *stream) {
+    return run(true, y_channel_last != 0, layout, dtype, ys, y, B, D, H, W, stream, "dirs_gather_ld", nullptr, row_pitch);
+}
+extern "C" int ss2d_dirs_gather6_ld(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, long long row_pitch,
+                                    void *stream) {
+    if (!ys2) { ss2d_set_error("dirs_gather6_ld: null pointer"); return -2; }
+    return run(true, false, SS2D_DIRS_MIRROR_FREE_4, dtype, ys4, y, B, D, H, W, stream, "dirs_gather6_ld", ys2, row_pitch);
 }

@@ -256,7 +256,7 @@ class ScanCoreFn(torch.autograd.Function):
         batch, K, Cx, L = x_dbl.shape
         Dch, R, N = dt_w.shape[1], dt_w.shape[2], A.shape[1]
         dim = 4 * Dch
-        if K != 4 or Cx != R + 2 * N or L != H * W or u2.shape != (batch, 2 * Dch, L) or dt_w.shape[0] != 4 or A.shape[0] != dim:
+        if K != 4 or Cx != R + 2 * N or L < H * W or u2.shape != (batch, 2 * Dch, L) or dt_w.shape[0] != 4 or A.shape[0] != dim:
             raise ValueError(f"scan_core_fn: inconsistent shapes u {tuple(u2.shape)} x_dbl {tuple(x_dbl.shape)} dt_w {tuple(dt_w.shape)}")
         if x is not None and tuple(x.shape) != (batch, Dch, H, W):
             raise ValueError(f"scan_core_fn: x {tuple(x.shape)} is not (batch, d, H, W) = {(batch, Dch, H, W)}")
@@ -298,8 +298,8 @@ class ScanCoreFn(torch.autograd.Function):
                                                      _lib.ptr(D_), None, _lib.ptr(bias_), _lib.ptr(out), None, _lib.ptr(ckpt),
                                                      batch, dim, L, N, 4, 1, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, bcs, _stream())
                 _lib.check(rc, "ss2d_selective_scan_dir_fwd")
-            rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(out), _lib.ptr(y), batch, Dch, H, W, 1, _stream())
-            _lib.check(rc, "ss2d_dirs_gather")
+            rc = lib.ss2d_dirs_gather_ld(code, 1, _lib.ptr(out), _lib.ptr(y), batch, Dch, H, W, 1, L, _stream())
+            _lib.check(rc, "ss2d_dirs_gather_ld")
         ctx.fused_delta = fused_delta
         ctx.save_for_backward(u_, delta, A_, xd, w32, D_, bias_, ckpt)
         ctx.meta = (code, H, W, R, u2.dtype, x_dbl.dtype, dt_w.dtype, A.dtype, None if D is None else D.dtype,
@@ -317,7 +317,7 @@ class ScanCoreFn(torch.autograd.Function):
         lib = _lib.load()
         g = dy.to(io).contiguous()
         dev = g.device
-        dys2 = torch.empty((batch, 2, Dch, L), device=dev, dtype=io)
+        dys2 = (torch.empty if L == H * W else torch.zeros)((batch, 2, Dch, L), device=dev, dtype=io)   # padded rows: dy = 0 in the pad
         du = torch.empty((batch, dim, L), device=dev, dtype=io)
         ddelta = torch.empty_like(du)
         sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
@@ -331,8 +331,8 @@ class ScanCoreFn(torch.autograd.Function):
             B_, C_, bcs = xd[:, :, R:R + N].contiguous(), xd[:, :, R + N:].contiguous(), N * L
         d_xdbl = torch.empty_like(xd)
         with _lib.on_device(dev):
-            rc = lib.ss2d_dirs_scatter(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, _stream())
-            _lib.check(rc, "ss2d_dirs_scatter")
+            rc = lib.ss2d_dirs_scatter_ld(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, L, _stream())
+            _lib.check(rc, "ss2d_dirs_scatter_ld")
             if ctx.fused_delta:
                 rc = lib.ss2d_selective_scan_core_bwd(code, _lib.ptr(u), _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(A), _lib.ptr(D),
                                                       _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du), _lib.ptr(ddelta),
@@ -353,8 +353,8 @@ class ScanCoreFn(torch.autograd.Function):
                 ctx.holder.du = du
             elif x_dt is not None:      # all four directions' du -> dx in one pass (the adjoint of the scatter)
                 dx = torch.empty((batch, Dch, H, W), device=dev, dtype=io)
-                rc = lib.ss2d_dirs_gather(code, 1, _lib.ptr(du), _lib.ptr(dx), batch, Dch, H, W, 0, _stream())
-                _lib.check(rc, "ss2d_dirs_gather")
+                rc = lib.ss2d_dirs_gather_ld(code, 1, _lib.ptr(du), _lib.ptr(dx), batch, Dch, H, W, 0, L, _stream())
+                _lib.check(rc, "ss2d_dirs_gather_ld")
             else:
                 du2 = du.view(batch, 2, 2, Dch, L).sum(2).view(batch, 2 * Dch, L)
             # dt_proj backward on library GEMMs (K = d contraction for d_dts, K = l for the weight)
@@ -377,5 +377,6 @@ def scan_core_fn(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None):
     """u2 (b, 2*d, l): row-major and column-major copies of x; x_dbl (b, 4, R+2N, l): the x_proj output with rows
     [dts | B | C] per scan group; dt_w (4, d, R); A (4*d, n), D, delta_bias (4*d) -- all in scan-group order
     (row-major, row-major reversed, column-major, column-major reversed).  delta = dt_w @ dts, softplus(delta + bias)
-    as in SS2D.  Returns y (b, H, W, d) = CrossMerge of the four scans."""
+    as in SS2D.  l may exceed H*W: rows padded by the caller, u2 zero in the pad (SS2D._scan_core_dirs).  Returns y
+    (b, H, W, d) = CrossMerge of the four scans."""
     return ScanCoreFn.apply(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x, holder)

@@ -144,11 +144,18 @@ class SS2D(nn.Module):
         # reference direction k = 2*rev + orientation  ->  scan group 2*orientation + rev: swap the two index bits
         # (plain views / one fused kernel; no index tensor, so the step stays HIP-graph capturable)
         slots = GradSlots() if (x.is_cuda and x.requires_grad and not os.environ.get("SS2D_NO_GATHER6")) else None     # du and d(xs2) meet in one gather (backward)
-        xs2 = dirs_scatter2(x, slots)                                                           # (B, 2, D, L)
+        core = x.dtype == torch.float32 or (self.bf16_scan_io and x.dtype == torch.bfloat16)
+        if core and L % 8 and x.is_cuda and not os.environ.get("SS2D_NO_ROW_PAD"):
+            # 7 x 7 (L = 49): rows padded to a multiple of 8 and zero in the pad, so that x_proj, dt_proj and the scan keep
+            # their aligned kernels.  u = 0 there: a reversed scan (which meets the pad first) stays at state 0 until the
+            # first real position, a forward scan reaches the pad behind the last one; x_dbl and dy are 0 in the pad, so no
+            # parameter gradient sees it, and the gathers read the H*W real positions only.
+            L = (L + 7) // 8 * 8
+        xs2 = dirs_scatter2(x, slots, L)                                                        # (B, 2, D, L)
         w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
         x_dbl = x_proj(w_cat, xs2).view(B, 4, Cx, L)                                    # group = 2*orientation + rev
         A, Dv, bias, dt_w = scan_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight, regroup=True)
-        if xs2.dtype == torch.float32 or (self.bf16_scan_io and xs2.dtype == torch.bfloat16):
+        if core:
             # dt_proj + scan + merge as one node reading x_dbl in place (rows [dts | B | C] of every block)
             return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x, holder=slots)
         # the reference's fp32 casts around the scan (:423-426) under autocast

@@ -678,25 +678,28 @@ class GradSlots:
 
 
 class _DirsScatter2(torch.autograd.Function):
-    """x (B, D, H, W) -> (B, 2, D, H*W): the row-major and the column-major copy only (layout MIRROR_FREE_2)."""
+    """x (B, D, H, W) -> (B, 2, D, pitch): the row-major and the column-major copy only (layout MIRROR_FREE_2); rows of
+    H*W positions, `pitch` apart, the pad zero."""
 
     @staticmethod
-    def forward(ctx, x, holder=None):
+    def forward(ctx, x, holder=None, pitch=None):
         _need_gpu(x, "dirs_scatter2")
         ctx.holder = holder
         B, D, H, W = x.shape
+        pitch = H * W if pitch is None else int(pitch)
         io, code = _io(x)
         xf = x.to(io).contiguous()
-        xs = torch.empty((B, 2, D, H * W), device=x.device, dtype=io)
+        xs = (torch.empty if pitch == H * W else torch.zeros)((B, 2, D, pitch), device=x.device, dtype=io)
         with _lib.on_device(x.device):
-            rc = _lib.load().ss2d_dirs_scatter(code, 2, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, 0, _stream())
-        _lib.check(rc, "ss2d_dirs_scatter")
-        ctx.shape, ctx.in_dtype = (B, D, H, W), x.dtype
+            rc = _lib.load().ss2d_dirs_scatter_ld(code, 2, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, 0, pitch, _stream())
+        _lib.check(rc, "ss2d_dirs_scatter_ld")
+        ctx.shape, ctx.in_dtype, ctx.pitch = (B, D, H, W), x.dtype, pitch
         return xs.to(x.dtype)
 
     @staticmethod
     def backward(ctx, dxs):
         B, D, H, W = ctx.shape
+        pitch = ctx.pitch
         io, code = _io(dxs)
         g = dxs.to(io).contiguous()
         dx = torch.empty((B, D, H, W), device=g.device, dtype=io)
@@ -704,25 +707,27 @@ class _DirsScatter2(torch.autograd.Function):
         if ctx.holder is not None:
             du, ctx.holder.du = ctx.holder.du, None
         with _lib.on_device(g.device):
-            if du is not None and du.dtype == io and tuple(du.shape) == (B, 4 * D, H * W) and du.is_contiguous():
-                rc = _lib.load().ss2d_dirs_gather6(code, _lib.ptr(du), _lib.ptr(g), _lib.ptr(dx), B, D, H, W, _stream())
+            if du is not None and du.dtype == io and tuple(du.shape) == (B, 4 * D, pitch) and du.is_contiguous():
+                rc = _lib.load().ss2d_dirs_gather6_ld(code, _lib.ptr(du), _lib.ptr(g), _lib.ptr(dx), B, D, H, W, pitch, _stream())
                 du = None
             else:
-                rc = _lib.load().ss2d_dirs_gather(code, 2, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, 0, _stream())
-        _lib.check(rc, "ss2d_dirs_gather")
+                rc = _lib.load().ss2d_dirs_gather_ld(code, 2, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, 0, pitch, _stream())
+        _lib.check(rc, "ss2d_dirs_gather_ld")
         if du is not None:      # a du this node could not fold in (dtype / shape): gather it the plain way and add
             dx2 = torch.empty_like(dx)
+            du = du.to(io).contiguous()
             with _lib.on_device(g.device):
-                rc = _lib.load().ss2d_dirs_gather(code, 1, _lib.ptr(du.to(io).contiguous()), _lib.ptr(dx2), B, D, H, W, 0, _stream())
-            _lib.check(rc, "ss2d_dirs_gather")
+                rc = _lib.load().ss2d_dirs_gather_ld(code, 1, _lib.ptr(du), _lib.ptr(dx2), B, D, H, W, 0, du.shape[-1], _stream())
+            _lib.check(rc, "ss2d_dirs_gather_ld")
             dx = dx + dx2
-        return dx.to(ctx.in_dtype), None
+        return dx.to(ctx.in_dtype), None, None
 
 
-def dirs_scatter2(x: torch.Tensor, holder=None) -> torch.Tensor:
+def dirs_scatter2(x: torch.Tensor, holder=None, pitch=None) -> torch.Tensor:
     """(B, D, H, W) -> (B, 2, D, H*W): x flattened row-major and column-major -- the two orientations of CrossScan
-    (mamba_sys.py:403); the two reversed directions (:404) are read from the same copies by the scan itself."""
-    return _DirsScatter2.apply(x, holder)
+    (mamba_sys.py:403); the two reversed directions (:404) are read from the same copies by the scan itself.  With
+    `pitch` > H*W the rows are that far apart and zero behind their H*W positions (see SS2D._scan_core_dirs)."""
+    return _DirsScatter2.apply(x, holder, pitch)
 
 
 class _DtProj(torch.autograd.Function):

@@ -294,6 +294,45 @@ def test_fused_directions_equal_literal_path(B, C, H, W):
         assert rel_l2(res[True][2][k].cpu(), res[False][2][k].cpu()) < 5e-5, k
 
 
+@pytest.mark.parametrize("B,C,H,W,dtype", [(2, 768, 7, 7, torch.float32), (3, 768, 7, 7, torch.bfloat16), (2, 192, 7, 7, torch.bfloat16),
+                                           (2, 96, 5, 9, torch.float32)])
+def test_padded_rows_equal_unpadded(B, C, H, W, dtype, monkeypatch):
+    """An odd H*W (the 7 x 7 stage): SS2D pads the rows of the direction side to a multiple of 8 (zero u, zero dy in the pad)
+    so that x_proj / dt_proj / the scan keep their aligned kernels -- output and every gradient against the same module
+    without the pad (SS2D_NO_ROW_PAD=1: unaligned rows, library GEMMs, the general scan backward)."""
+    from mamba_unet_amd import SS2D
+    torch.manual_seed(C + H)
+    m = SS2D(d_model=C).cuda()
+    with torch.no_grad():
+        m.A_logs.add_(torch.randn_like(m.A_logs) * 0.3)
+        m.Ds.mul_(torch.rand_like(m.Ds) + 0.5)
+    x = torch.randn(B, H, W, C, device="cuda")
+    g = torch.randn(B, H, W, C, device="cuda")
+    res = {}
+    old = SS2D.bf16_scan_io
+    try:
+        SS2D.bf16_scan_io = dtype == torch.bfloat16
+        for pad in (False, True):
+            if pad:
+                monkeypatch.delenv("SS2D_NO_ROW_PAD", raising=False)
+            else:
+                monkeypatch.setenv("SS2D_NO_ROW_PAD", "1")
+            xi = x.clone().requires_grad_(True)
+            m.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+                y = m(xi)
+            y.float().backward(g)
+            res[pad] = (y.detach().float(), xi.grad, {k: p.grad.clone() for k, p in m.named_parameters()})
+    finally:
+        SS2D.bf16_scan_io = old
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2        # bf16: two roundings of different intermediate tensors
+    assert rel_l2(res[True][0].cpu(), res[False][0].cpu()) < tol
+    assert rel_l2(res[True][1].cpu(), res[False][1].cpu()) < 2 * tol
+    for k in res[True][2]:
+        assert torch.isfinite(res[True][2][k]).all(), k
+        assert rel_l2(res[True][2][k].cpu(), res[False][2][k].cpu()) < 3 * tol, k
+
+
 @pytest.mark.parametrize("B,G,D,R,L,dtype", [(2, 4, 192, 6, 3136, torch.float32), (1, 4, 384, 12, 784, torch.float32),
                                              (3, 4, 16, 6, 20, torch.float32), (2, 4, 192, 6, 3136, torch.bfloat16)])
 def test_dt_proj_kernel(B, G, D, R, L, dtype):
