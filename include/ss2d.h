@@ -316,6 +316,14 @@ int ss2d_chan_gemm(int dtype, const void *W, const void *X, void *Y, int B, int 
  * aligned.  SS2D_DTYPE_BF16 only (fp32 callers use the BLAS library). */
 int ss2d_token_gemm(int dtype, const void *A, const void *B, void *C, long long T, int N, int K, int lda, int ldb, int ldc,
                     int b_k_major, void *stream);
+/* The same forward product over a CONCATENATED input, without the concatenation, and with the bias:
+ *   C (T x N) = [A | A2] (T x (K1 + K2)) * W^T + bias      W (N x K) row-major with leading dimension ldw, K = K1 + K2
+ * -- `self.concat_back_dim[inx](torch.cat([x, x_downsample[3 - inx]], -1))` (mamba_sys.py:835, the nn.Linear(2*dim, dim) of
+ * :774-778).  bias (N) fp32 is added before the result is rounded to bf16; nullable.  A2 may be null with K1 == K (a plain
+ * biased Linear).  K1 must be a multiple of the kernel's k chunk (32 for K <= 256, else 64); the other conditions are those
+ * of ss2d_token_gemm. */
+int ss2d_token_gemm_cat(int dtype, const void *A, const void *A2, const void *W, const float *bias, void *C, long long T, int N,
+                        int K, int K1, int lda, int lda2, int ldw, int ldc, void *stream);
 
 /* Column sums out[j] = sum_r x[r*ldx + j] (fp32) of a (rows, M) matrix in dtype: autograd's bias gradient of the Linears
  * that have a bias (`concat_back_dim`, mamba_sys.py:774-778, applied :835).  Deterministic (per-workgroup partial rows in

@@ -23,10 +23,11 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 struct TgParams {
-    const bf16 *A, *B;
+    const bf16 *A, *A2, *B;     // A2: the token operand of k >= K1 (the skip half of a concatenated input), or A again
+    const float *bias;          // (N) fp32, added before the result is rounded; nullable
     bf16 *C;
     long long T;
-    int N, K, lda, ldb, ldc, tiles_n;
+    int N, K, K1, lda, lda2, ldb, ldc, tiles_n;
 };
 
 constexpr int GT = 128, GN = 96;                          // tokens, columns per workgroup
@@ -65,11 +66,16 @@ __global__ __launch_bounds__(256) void tok_gemm_kernel(const TgParams p) {
     }
     auto load_chunk = [&](int k0) {
         // never a guarded load: the address is clamped to element 0 and the value masked
+        // K1 is a multiple of GK: a chunk lies in one of the two token operands (scalar choice)
+        const bool second = k0 >= p.K1;
+        const bf16 *__restrict__ Ap = second ? p.A2 : p.A;
+        const long long lda = second ? p.lda2 : p.lda;
+        const int ka = (second ? k0 - p.K1 : k0) + acol;
 #pragma unroll
         for (int j = 0; j < NAP; ++j) {
             const long long t = t0 + arow + (256 / APR) * j;
             const bool ok = t < p.T && k0 + acol < p.K;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(p.A + (ok ? t * p.lda + k0 + acol : 0));
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(Ap + (ok ? t * lda + ka : 0));
             pa[j] = v & (ok ? ~0u : 0u);
         }
 #pragma unroll
@@ -135,6 +141,12 @@ __global__ __launch_bounds__(256) void tok_gemm_kernel(const TgParams p) {
     for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if (p.bias) {       // N % 8 == 0: the four columns are inside N together
+                const int n = n0 + 32 * j + 8 * g + 4 * half;
+                const f4 bv = *reinterpret_cast<const f4 *>(p.bias + (n < p.N ? n : 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[j][4 * g + i] += bv[i];
+            }
             const bf16x4 v = {(__bf16)acc[j][4 * g], (__bf16)acc[j][4 * g + 1], (__bf16)acc[j][4 * g + 2], (__bf16)acc[j][4 * g + 3]};
             *reinterpret_cast<bf16x4 *>(lds + (32 * wave + l32) * CROW + (32 * j + 8 * g + 4 * half) * 2) = v;
         }
@@ -150,24 +162,42 @@ __global__ __launch_bounds__(256) void tok_gemm_kernel(const TgParams p) {
 
 }  // namespace
 
-extern "C" int ss2d_token_gemm(int dtype, const void *A, const void *B, void *C, long long T, int N, int K, int lda, int ldb,
-                               int ldc, int b_k_major, void *stream) {
-    if (dtype != SS2D_DTYPE_BF16) { ss2d_set_error("token_gemm: bf16 only (dtype %d)", dtype); return -1; }
-    if (!A || !B || !C) { ss2d_set_error("token_gemm: null required pointer"); return -2; }
-    if (T <= 0 || N <= 0 || K <= 0 || lda < K || ldc < N || ldb < (b_k_major ? N : K)) { ss2d_set_error("token_gemm: bad size"); return -3; }
-    if (N % 8 || K % 8 || lda % 8 || ldb % 8 || ldc % 8 || ((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) != 0)) {
-        ss2d_set_error("token_gemm: N, K, the leading dimensions must be multiples of 8 and the operands 16-byte aligned"); return -4; }
+namespace {
+int tg_run(const char *name, int dtype, const void *A, const void *A2, const void *B, const float *bias, void *C, long long T, int N, int K,
+           int K1, int lda, int lda2, int ldb, int ldc, int b_k_major, void *stream) {
+    if (dtype != SS2D_DTYPE_BF16) { ss2d_set_error("%s: bf16 only (dtype %d)", name, dtype); return -1; }
+    if (!A || !B || !C || (K1 < K && !A2)) { ss2d_set_error("%s: null required pointer", name); return -2; }
+    if (T <= 0 || N <= 0 || K <= 0 || K1 <= 0 || K1 > K || lda < K1 || (K1 < K && lda2 < K - K1) || ldc < N || ldb < (b_k_major ? N : K)) {
+        ss2d_set_error("%s: bad size", name); return -3; }
+    if (N % 8 || K % 8 || lda % 8 || ldb % 8 || ldc % 8 || (K1 < K && lda2 % 8) ||
+        ((((uintptr_t)A | (uintptr_t)(K1 < K ? A2 : A) | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) != 0)) {
+        ss2d_set_error("%s: N, K, the leading dimensions must be multiples of 8 and the operands 16-byte aligned", name); return -4; }
+    const bool k64 = K > 256;
+    if (K1 < K && K1 % (k64 ? 64 : 32)) { ss2d_set_error("%s: K1 must be a multiple of the k chunk (%d)", name, k64 ? 64 : 32); return -4; }
     TgParams p;
-    p.A = static_cast<const bf16 *>(A); p.B = static_cast<const bf16 *>(B); p.C = static_cast<bf16 *>(C);
-    p.T = T; p.N = N; p.K = K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.A = static_cast<const bf16 *>(A); p.A2 = static_cast<const bf16 *>(K1 < K ? A2 : A); p.B = static_cast<const bf16 *>(B);
+    p.bias = bias; p.C = static_cast<bf16 *>(C);
+    p.T = T; p.N = N; p.K = K; p.K1 = K1; p.lda = lda; p.lda2 = K1 < K ? lda2 : lda; p.ldb = ldb; p.ldc = ldc;
     p.tiles_n = (N + GN - 1) / GN;
     const long long nwg = ((T + GT - 1) / GT) * p.tiles_n;
-    if (nwg > 0x7fffffffLL) { ss2d_set_error("token_gemm: grid too large"); return -6; }
+    if (nwg > 0x7fffffffLL) { ss2d_set_error("%s: grid too large", name); return -6; }
     hipStream_t s = (hipStream_t)stream;
-    const bool k64 = K > 256;
     if (b_k_major) { if (k64) ss2d_launch((tok_gemm_kernel<true, 64>), dim3((unsigned)nwg), dim3(256), 0, s, p); else ss2d_launch((tok_gemm_kernel<true, 32>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
     else { if (k64) ss2d_launch((tok_gemm_kernel<false, 64>), dim3((unsigned)nwg), dim3(256), 0, s, p); else ss2d_launch((tok_gemm_kernel<false, 32>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
     const int rc = ss2d_take_launch_rc();
-    if (rc) ss2d_set_error("token_gemm: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
     return rc;
+}
+}  // namespace
+
+extern "C" int ss2d_token_gemm(int dtype, const void *A, const void *B, void *C, long long T, int N, int K, int lda, int ldb,
+                               int ldc, int b_k_major, void *stream) {
+    return tg_run("token_gemm", dtype, A, nullptr, B, nullptr, C, T, N, K, K, lda, 0, ldb, ldc, b_k_major, stream);
+}
+
+// C (T x N) = [A | A2] (T x (K1 + K2)) * W^T + bias: a Linear over a concatenated input without the concatenation, the bias
+// added in fp32 before the result is rounded.  A2 may be null with K1 == K (a plain biased Linear).
+extern "C" int ss2d_token_gemm_cat(int dtype, const void *A, const void *A2, const void *W, const float *bias, void *C, long long T,
+                                   int N, int K, int K1, int lda, int lda2, int ldw, int ldc, void *stream) {
+    return tg_run("token_gemm_cat", dtype, A, A2, W, bias, C, T, N, K, K1, lda, lda2, ldw, ldc, 0, stream);
 }

@@ -361,6 +361,40 @@ def _token_gemm_pays(tokens: int, n: int, k: int) -> bool:
     return _OWN_TOKEN_GEMM and not (k >= 1536 and ((tokens + 127) // 128) * ((n + 95) // 96) < 256)
 
 
+def token_gemm_cat(a: torch.Tensor, a2, w: torch.Tensor, bias):
+    """[a | a2] @ w.T + bias in bf16 (fp32 accumulation, fp32 bias added before rounding) without the concatenation --
+    csrc/ss2d_tokgemm.hip.  a (..., K1), a2 (..., K2) or None, w (N, K1 + K2), bias (N) fp32 or None.  None when dtype /
+    layout do not qualify."""
+    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not a.is_cuda or w.dim() != 2:
+        return None
+    K1 = a.shape[-1]
+    K2 = 0 if a2 is None else a2.shape[-1]
+    N, K = w.shape
+    if K != K1 + K2 or K % 8 or N % 8 or w.stride(1) != 1 or w.stride(0) % 8 or w.data_ptr() % 16:
+        return None
+    if a2 is not None and (a2.dtype != torch.bfloat16 or a2.shape[:-1] != a.shape[:-1] or K1 % (64 if K > 256 else 32)):
+        return None
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16 or bias.numel() != N):
+        return None
+    ops = []
+    for t in (a, a2):
+        if t is None:
+            ops.append((None, 0))
+            continue
+        t2 = t.reshape(-1, t.shape[-1])
+        ld = t2.stride(0) if t2.shape[0] > 1 else t2.shape[1]
+        if t2.shape[0] == 0 or t2.stride(1) != 1 or t2.data_ptr() % 16 or ld % 8 or ld < t2.shape[1]:
+            return None
+        ops.append((t2, ld))
+    (a_, lda), (a2_, lda2) = ops
+    out = torch.empty((a_.shape[0], N), device=a.device, dtype=torch.bfloat16)
+    with _lib.on_device(a.device):
+        rc = _lib.load().ss2d_token_gemm_cat(_BF16, _lib.ptr(a_), _lib.ptr(a2_), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), a_.shape[0],
+                                             N, K, K1, lda, lda2, w.stride(0), N, _stream())
+    _lib.check(rc, "ss2d_token_gemm_cat")
+    return out.view(*a.shape[:-1], N)
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T (+ b) for the Linears whose token axis dwarfs both feature axes: bf16 forward and dX on the token-major
     MFMA kernel (ss2d_token_gemm; hipBLASLt for fp32, with a bias, and where _token_gemm_pays says no), dW on the
@@ -376,8 +410,9 @@ class _Linear(torch.autograd.Function):
             w, b = weight, bias
         ctx.save_for_backward(x, w)
         ctx.w_dtype, ctx.b_dtype = weight.dtype, None if bias is None else bias.dtype
-        own = b is None and _token_gemm_pays(x.numel() // x.shape[-1], w.shape[0], w.shape[1])
-        y = token_gemm(x, w, False) if own else None                                   # bf16, bias-free: own MFMA kernel
+        y = None
+        if _token_gemm_pays(x.numel() // x.shape[-1], w.shape[0], w.shape[1]):           # bf16: own MFMA kernel
+            y = token_gemm(x, w, False) if b is None else token_gemm_cat(x, None, w, bias if bias.dtype == torch.float32 else None)
         if y is not None:
             return y
         with torch.autocast("cuda", enabled=False):
@@ -420,6 +455,11 @@ class _ConcatLinear(torch.autograd.Function):
         C1 = x.shape[-1]
         ctx.save_for_backward(x, skip, w)
         ctx.w_dtype, ctx.b_dtype = weight.dtype, None if bias is None else bias.dtype
+        y = None
+        if _token_gemm_pays(x.numel() // C1, w.shape[0], w.shape[1]) and (bias is None or bias.dtype == torch.float32):
+            y = token_gemm_cat(x, skip, w, bias)                       # both halves and the bias in one pass
+        if y is not None:
+            return y
         with torch.autocast("cuda", enabled=False):
             y = torch.nn.functional.linear(x, w[:, :C1], b)
             y.view(-1, y.shape[-1]).addmm_(skip.reshape(-1, skip.shape[-1]), w[:, C1:].t())

@@ -471,7 +471,29 @@ def test_colsum_matches_fp64(rows, M, ldx, dtype):
     assert torch.equal(got, colsum(wide.cuda()[:, :M]))          # deterministic
 
 
-@pytest.mark.parametrize("B,H,W,C,dtype", [(2, 56, 56, 96, torch.float32), (2, 14, 14, 384, torch.float32), (3, 28, 28, 192, torch.bfloat16)])
+@pytest.mark.parametrize("T,N,K1,K2,bias", [(3136, 96, 96, 96, True), (777, 192, 192, 192, True), (130, 384, 384, 384, False),
+                                            (1000, 104, 64, 40, True), (257, 96, 264, 0, True), (64, 8, 8, 0, True)])
+def test_token_gemm_cat(T, N, K1, K2, bias):
+    """[a | a2] @ w.T + bias (the decoder's concat Linear, mamba_sys.py:835, and a plain biased Linear with a2 = None) in
+    bf16 against an fp64 product of the same bf16 values + the fp32 bias: result rounded once."""
+    from mamba_unet_amd.ss2d_ops import token_gemm_cat
+    gen = torch.Generator().manual_seed(T + N + K1 + K2)
+    a = torch.randn(T, K1, generator=gen).to(torch.bfloat16)
+    a2 = torch.randn(T, K2, generator=gen).to(torch.bfloat16) if K2 else None
+    w = (torch.randn(N, K1 + K2, generator=gen) * 0.2).to(torch.bfloat16)
+    b = torch.randn(N, generator=gen) if bias else None
+    got = token_gemm_cat(a.cuda(), None if a2 is None else a2.cuda(), w.cuda(), None if b is None else b.cuda())
+    assert got is not None and got.shape == (T, N) and got.dtype == torch.bfloat16
+    full = a.double() if a2 is None else torch.cat([a.double(), a2.double()], -1)
+    want = full @ w.double().t() + (0 if b is None else b.double())
+    assert rel_l2(got.float().cpu(), want) < 4e-3
+    assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    if K2:   # K1 must be a multiple of the kernel's k chunk: anything else is refused, not computed wrongly
+        assert token_gemm_cat(a.cuda()[:, :K1 - 8].contiguous(), a2.cuda(), w.cuda()[:, 8:].contiguous(), None) is None
+
+
+@pytest.mark.parametrize("B,H,W,C,dtype", [(2, 56, 56, 96, torch.float32), (2, 14, 14, 384, torch.float32), (3, 28, 28, 192, torch.bfloat16),
+                                           (3, 56, 56, 96, torch.bfloat16), (2, 14, 14, 384, torch.bfloat16)])
 def test_concat_linear_matches_cat_then_linear(B, H, W, C, dtype):
     """The decoder's skip connection (mamba_sys.py:835): Linear(cat([x, skip])) without the concatenated tensor."""
     from mamba_unet_amd.ss2d_ops import concat_linear
