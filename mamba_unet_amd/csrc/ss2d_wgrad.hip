@@ -16,6 +16,7 @@
 // gradient keeps fp32 products and sums, at 16x the MFMA rate; that kernel is bound by its reads
 // (stage 0 in_proj: 27 us of loop for 72 MB, plus ~10 us of reduction and atomics).
 #include <cstdlib>
+#include <type_traits>
 #include "ss2d_common.h"
 #include "../../include/ss2d.h"
 
@@ -324,33 +325,39 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p)
     const bf16 *__restrict__ A = static_cast<const bf16 *>(p.A);
     const bf16 *__restrict__ B = static_cast<const bf16 *>(p.B);
     // this thread's pieces of a chunk: 4 of A (64 rows x 16 pieces), 3 of B (64 rows x 12 pieces)
-    u32x4 pa[4], pb[3];
+    // TWO chunks are in flight in registers (set = stage = chunk parity): with one, every chunk waited a full memory round
+    // trip -- a workgroup is alone on its CU (about one per CU is launched) and the MFMAs of a chunk take a fraction of that
+    u32x4 pa[2][4], pb[2][3];
     int brow[3], bcol[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { const int id = j * 256 + tid; brow[j] = id / 12; bcol[j] = (id - brow[j] * 12) * 8; }
     const int arow = tid >> 4, acol = (tid & 15) * 8;          // piece j: row arow + 16 j
-    auto load_chunk = [&](long long rc) {
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    auto load_chunk = [&](auto set, long long rc) {              // rows at or past r1 (also whole chunks) read as zeros
+        constexpr int S = decltype(set)::value;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const long long row = rc + arow + 16 * j;
             const bool ok = row < r1 && m0 + acol < p.M;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(A + (ok ? row * p.lda + m0 + acol : 0));
-            pa[j] = v & (ok ? ~0u : 0u);
+            pa[S][j] = v & (ok ? ~0u : 0u);
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const long long row = rc + brow[j];
             const bool ok = row < r1 && n0 + bcol[j] < p.N;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(B + (ok ? row * p.ldb + n0 + bcol[j] : 0));
-            pb[j] = v & (ok ? ~0u : 0u);
+            pb[S][j] = v & (ok ? ~0u : 0u);
         }
     };
-    auto put_chunk = [&](int s) {
-        unsigned char *as = lds + s * TSTAGE, *bs = as + TKC * TAROW;
+    auto put_chunk = [&](auto set) {
+        constexpr int S = decltype(set)::value;
+        unsigned char *as = lds + S * TSTAGE, *bs = as + TKC * TAROW;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4 *>(as + (arow + 16 * j) * TAROW + acol * 2) = pa[j];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4 *>(as + (arow + 16 * j) * TAROW + acol * 2) = pa[S][j];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4 *>(bs + brow[j] * TBROW + bcol[j] * 2) = pb[j];
+        for (int j = 0; j < 3; ++j) *reinterpret_cast<u32x4 *>(bs + brow[j] * TBROW + bcol[j] * 2) = pb[S][j];
     };
     f16v acc[3];
 #pragma unroll
@@ -364,12 +371,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p)
     const int aoff = trow * TAROW + 64 * wave + tcol, boff = trow * TBROW + tcol;
     const bool live = m0 + 32 * wave < p.M;                     // a wave whose rows lie past M multiplies nothing
     const long long nchunks = r1 > r0 ? (r1 - r0 + TKC - 1) / TKC : 0;
-    if (nchunks > 0) load_chunk(r0);
-    for (long long c = 0; c < nchunks; ++c) {
-        const int s = (int)(c & 1);
-        put_chunk(s);                                              // stage s was last read two chunks ago, behind the previous barrier
-        load_chunk(r0 + (c + 1 < nchunks ? c + 1 : c) * TKC);      // in flight during the MFMAs (the last one is a harmless repeat)
-        __syncthreads();
+    auto products = [&](auto set) {
+        constexpr int s = decltype(set)::value;
         if (live) {
             typedef s16x4 __attribute__((address_space(3))) *lp;
             const unsigned char *as = lds + s * TSTAGE + aoff, *bs = lds + s * TSTAGE + TKC * TAROW + boff;
@@ -387,6 +390,19 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p)
                 }
             }
         }
+    };
+    if (nchunks > 0) { load_chunk(S0, r0); load_chunk(S1, r0 + TKC); }
+    // two chunks per trip, nothing under a branch (an odd count ends with a chunk of zeros); a stage was last read two chunks
+    // ago, behind the previous barrier
+    for (long long c = 0; c < nchunks; c += 2) {
+        put_chunk(S0);
+        load_chunk(S0, r0 + (c + 2) * TKC);
+        __syncthreads();
+        products(S0);
+        put_chunk(S1);
+        load_chunk(S1, r0 + (c + 3) * TKC);
+        __syncthreads();
+        products(S1);
     }
 #ifndef SS2D_WGRAD_NOATOMICS   // (timing experiments only)
     // accumulator register e of a 32x32 block: row = 8*(e/4) + 4*(lane/32) + e%4, column = lane%32
