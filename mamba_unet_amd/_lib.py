@@ -113,7 +113,7 @@ class _Here:
         return False
 
 
-_HERE = _Here()
+_NO_CTX = _Here()
 
 
 def on_device(dev):
@@ -123,7 +123,7 @@ def on_device(dev):
     import torch
     idx = dev.index
     if idx is None or idx == torch.cuda.current_device():
-        return _HERE
+        return _NO_CTX
     return torch.cuda.device(dev)
 
 
