@@ -43,6 +43,8 @@ def parser():
     ap.add_argument("--graph", action="store_true",
                     help="1 GPU.  infer: replay the forward from a HIP graph (checked against eager at capture).  train: "
                          "the whole step (forward, loss, backward, SGD) captured once and replayed")
+    ap.add_argument("--no-weight-copies", action="store_true",
+                    help="A/B switch: cast every Linear weight to bf16 in every step instead of refreshing working copies once per optimizer step")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -72,7 +74,7 @@ def run(args, rank, world, local, dist):
     dev = torch.device("cuda", local)
     from mamba_unet_amd import MambaUnet
     from mamba_unet_amd.dist import wrap_ddp
-    from mamba_unet_amd.train import GraphedSupervisedStep, make_sgd, semi_step, supervised_step
+    from mamba_unet_amd.train import GraphedSupervisedStep, WeightCopies, make_sgd, semi_step, supervised_step
 
     bf16 = args.dtype != "fp32"
     from mamba_unet_amd import SS2D
@@ -107,18 +109,21 @@ def run(args, rank, world, local, dist):
         net = wrap_ddp(nets[0].train(), local)
         if args.graph and world == 1:
             opt = make_sgd(net.parameters(), tensor_lr_device=dev)
+            copies = WeightCopies(net, opt) if (bf16 and not args.no_weight_copies) else None     # noqa: F841 (kept alive)
             gstep = GraphedSupervisedStep(net, opt, images, labels, args.classes, max_it, autocast_bf16=bf16)
 
             def step(it):
                 return gstep(gstep.images, gstep.labels, it)
         else:
             opt = make_sgd(net.parameters())
+            copies = WeightCopies(net, opt) if (bf16 and not args.no_weight_copies) else None     # noqa: F841 (kept alive)
 
             def step(it):
                 return supervised_step(net, opt, images, labels, args.classes, it, max_it, autocast_bf16=bf16)
     else:
         n1, n2 = (wrap_ddp(n.train(), local) for n in nets)
         o1, o2 = make_sgd(n1.parameters()), make_sgd(n2.parameters())
+        copies = [WeightCopies(n, o) for n, o in ((n1, o1), (n2, o2))] if (bf16 and not args.no_weight_copies) else None     # noqa: F841
 
         def step(it):
             return semi_step(n1, n2, o1, o2, images, labels, args.batch // 2, args.classes, it, max_it, 0.1, autocast_bf16=bf16)

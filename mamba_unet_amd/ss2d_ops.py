@@ -361,6 +361,22 @@ def _token_gemm_pays(tokens: int, n: int, k: int) -> bool:
     return _OWN_TOKEN_GEMM and not (k >= 1536 and ((tokens + 127) // 128) * ((n + 95) // 96) < 256)
 
 
+_WORKING_COPIES = {}      # id(parameter) -> (weakref to it, low-precision copy, parameter._version when the copy was made)
+
+
+def cast_weight(p: torch.Tensor, dt) -> torch.Tensor:
+    """p.to(dt) -- or the registered working copy of the parameter (train.WeightCopies: the fp32 master / bf16 working copy
+    arrangement of mixed-precision training, refreshed once per optimizer step by ONE multi-tensor kernel instead of a cast
+    kernel per Linear and step).  A copy is used only while the parameter's version counter still has the value it had at
+    the refresh; any in-place update since (optimizer, load_state_dict, copy_) falls back to the cast."""
+    if p.dtype == dt:
+        return p
+    e = _WORKING_COPIES.get(id(p))
+    if e is not None and e[0]() is p and e[1].dtype == dt and e[2] == p._version:
+        return e[1]
+    return p.to(dt)
+
+
 def token_gemm_cat(a: torch.Tensor, a2, w: torch.Tensor, bias):
     """[a | a2] @ w.T + bias in bf16 (fp32 accumulation, fp32 bias added before rounding) without the concatenation --
     csrc/ss2d_tokgemm.hip.  a (..., K1), a2 (..., K2) or None, w (N, K1 + K2), bias (N) fp32 or None.  None when dtype /
@@ -404,7 +420,7 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype("cuda")
-            x, w = x.to(dt), weight.to(dt)
+            x, w = x.to(dt), cast_weight(weight, dt)
             b = None if bias is None else bias.to(dt)
         else:
             w, b = weight, bias
@@ -447,7 +463,7 @@ class _ConcatLinear(torch.autograd.Function):
     def forward(ctx, x, skip, weight, bias):
         if torch.is_autocast_enabled():
             dt = torch.get_autocast_dtype("cuda")
-            x, skip, w = x.to(dt), skip.to(dt), weight.to(dt)
+            x, skip, w = x.to(dt), skip.to(dt), cast_weight(weight, dt)
             b = None if bias is None else bias.to(dt)
         else:
             w, b = weight, bias

@@ -78,6 +78,17 @@ class CapturableSGD:
         self.param_groups = [{"lr": torch.tensor(float(lr), device=device), "momentum": momentum,
                               "weight_decay": weight_decay, "params": self.params}]
         self.bufs = {}
+        self._post_hooks = {}
+
+    def register_step_post_hook(self, hook):
+        """hook(optimizer, args, kwargs) after every step(), as torch.optim.Optimizer has it; returns a handle with .remove()."""
+        key = object()
+        self._post_hooks[key] = hook
+
+        class _Handle:
+            def remove(_self):
+                self._post_hooks.pop(key, None)
+        return _Handle()
 
     def zero_grad(self, set_to_none=True):
         for p in self.params:
@@ -102,6 +113,8 @@ class CapturableSGD:
             torch._foreach_add_(ob, [t for _, t in old])
         bufs = [self.bufs[id(p)] for p in ps]
         torch._foreach_sub_(ps, torch._foreach_mul(bufs, g["lr"]))
+        for hook in list(self._post_hooks.values()):
+            hook(self, (), {})
 
     def state_dict(self):
         """Momentum buffers by parameter position (the order of the constructor's `params`) and the learning rate."""
@@ -144,6 +157,45 @@ def supervised_step(model, optimizer, images, labels, n_classes, it, max_it, bas
     optimizer.step()
     set_lr(optimizer, poly_lr(base_lr, it, max_it))
     return loss.detach()
+
+
+class WeightCopies:
+    """bf16 working copies of a model's Linear weights for autocast training (fp32 master weights stay the parameters):
+    `WeightCopies(model, optimizer)` makes the copies, refreshes them after every `optimizer.step()` (a step post-hook:
+    ONE multi-tensor cast instead of a cast kernel per Linear per step, 42 of them in MambaUNet) and registers them with
+    ss2d_ops.cast_weight, which the Linear functions of this package consult.  A copy is ignored as soon as its
+    parameter's version counter moves without a refresh, so `load_state_dict` or a second optimizer cannot make it stale;
+    an update through `.data` (the EMA idiom of the reference's mean-teacher scripts) does not move the counter -- do not
+    attach WeightCopies to a model updated that way, or call refresh() after the update.  close() unregisters."""
+
+    def __init__(self, model, optimizer=None, dtype=torch.bfloat16):
+        seen, self.params = set(), []
+        for m in model.modules():
+            if type(m) is torch.nn.Linear and m.weight.dtype == torch.float32 and id(m.weight) not in seen:
+                seen.add(id(m.weight))
+                self.params.append(m.weight)
+        self.copies = [torch.empty_like(p, dtype=dtype) for p in self.params]
+        self.hook = optimizer.register_step_post_hook(lambda *_: self.refresh()) if optimizer is not None else None
+        self.refresh()
+
+    def refresh(self):
+        import weakref
+        from . import ss2d_ops
+        if not self.params:
+            return
+        with torch.no_grad():
+            torch._foreach_copy_(self.copies, self.params)
+        for p, c in zip(self.params, self.copies):
+            ss2d_ops._WORKING_COPIES[id(p)] = (weakref.ref(p), c, p._version)
+
+    def close(self):
+        from . import ss2d_ops
+        if self.hook is not None:
+            self.hook.remove()
+            self.hook = None
+        for p in self.params:
+            ss2d_ops._WORKING_COPIES.pop(id(p), None)
+        self.params, self.copies = [], []
 
 
 class GraphedSupervisedStep:

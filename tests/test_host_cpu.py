@@ -141,3 +141,31 @@ def test_ce_dice_from_stats_reproduces_reference_losses():
         stats = torch.cat([(p * oh).sum((0, 2, 3)), oh.sum((0, 2, 3)), (p * p).sum((0, 2, 3)), ce.view(1)])
         ce_m, dice = ce_dice_from_stats(stats, logits.numel() // C, C, global_batch=False)
         assert abs(float(0.5 * (ce_m + dice)) - float(g[tag + ".loss"])) < 1e-6
+
+
+def test_weight_copies_follow_the_optimizer_and_never_go_stale():
+    """train.WeightCopies: the bf16 working copy is what ss2d_ops.cast_weight returns right after a refresh, is refreshed by
+    the optimizer's step hook, and is ignored (fresh cast instead) after any other in-place update of the parameter."""
+    import torch
+    from mamba_unet_amd import ss2d_ops
+    from mamba_unet_amd.train import WeightCopies
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(16, 8, bias=False), torch.nn.ReLU(), torch.nn.Linear(8, 4))
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    wc = WeightCopies(net, opt)
+    w = net[0].weight
+    c0 = ss2d_ops.cast_weight(w, torch.bfloat16)
+    assert c0 is wc.copies[0] and torch.equal(c0, w.detach().to(torch.bfloat16))
+    assert ss2d_ops.cast_weight(w, torch.float32) is w
+    net(torch.randn(5, 16)).sum().backward()
+    opt.step()                                                  # hook: refreshed in place
+    c1 = ss2d_ops.cast_weight(w, torch.bfloat16)
+    assert c1 is wc.copies[0] and torch.equal(c1, w.detach().to(torch.bfloat16))
+    with torch.no_grad():
+        w.mul_(2.0)                                             # an update the hook does not see: the copy must not be used
+    c2 = ss2d_ops.cast_weight(w, torch.bfloat16)
+    assert c2 is not wc.copies[0] and torch.equal(c2, w.detach().to(torch.bfloat16))
+    wc.refresh()
+    assert ss2d_ops.cast_weight(w, torch.bfloat16) is wc.copies[0]
+    wc.close()
+    assert ss2d_ops.cast_weight(w, torch.bfloat16) is not c0 and id(w) not in ss2d_ops._WORKING_COPIES
