@@ -190,13 +190,30 @@ __global__ __launch_bounds__(256) void cross_merge_kernel(const CrossParams p) {
     }
 }
 
-// ---- vector variants: every lane moves 4 consecutive elements along the fast axis of the phase (w, h or d),
-// i.e. 16-byte (fp32) / 8-byte (bf16) global accesses; the LDS tile and its odd strides are those of the scalar
-// kernels above.  Require H % 4 == 0, W % 4 == 0 (and D % 4 == 0 on a channel-last side) and aligned pointers;
-// the host falls back to the scalar kernels otherwise (14x14 and 7x7 stages).
+// ---- vector variants: every lane moves E = 4 (or 2, for the 14 x 14 stage) consecutive elements along the fast axis of
+// the phase (w, h or d), i.e. 16- / 8-byte (fp32) or 8- / 4-byte (bf16) global accesses; the LDS tile and its odd strides are
+// those of the scalar kernels above.  Require H % E == 0, W % E == 0, a row pitch % E == 0 (and D % E == 0 on a channel-last
+// side) and aligned pointers; the host falls back to the scalar kernels otherwise (the 7 x 7 stage).
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+template <int E> struct VecOf;
+template <> struct VecOf<4> { typedef f4 type; };
+template <> struct VecOf<2> { typedef f2v type; };
 __device__ __forceinline__ f4 rev4(f4 v) { return f4{v.w, v.z, v.y, v.x}; }
+template <int E> __device__ __forceinline__ typename VecOf<E>::type revv(typename VecOf<E>::type v);
+template <> __device__ __forceinline__ f4 revv<4>(f4 v) { return rev4(v); }
+template <> __device__ __forceinline__ f2v revv<2>(f2v v) { return f2v{v.y, v.x}; }
+template <int E> __device__ __forceinline__ typename VecOf<E>::type ldv(const float *p) { return *reinterpret_cast<const typename VecOf<E>::type *>(p); }
+template <int E> __device__ __forceinline__ typename VecOf<E>::type ldv(const bf16 *p);
+template <> __device__ __forceinline__ f4 ldv<4>(const bf16 *p) { return ld4(p); }
+template <> __device__ __forceinline__ f2v ldv<2>(const bf16 *p) { return __builtin_convertvector(*reinterpret_cast<const bf16x2v *>(p), f2v); }
+template <int E> __device__ __forceinline__ void stv(float *p, typename VecOf<E>::type v) { *reinterpret_cast<typename VecOf<E>::type *>(p) = v; }
+__device__ __forceinline__ void stv4b(bf16 *p, f4 v) { st4(p, v); }
+template <int E> __device__ __forceinline__ void stv(bf16 *p, typename VecOf<E>::type v);
+template <> __device__ __forceinline__ void stv<4>(bf16 *p, f4 v) { st4(p, v); }
+template <> __device__ __forceinline__ void stv<2>(bf16 *p, f2v v) { *reinterpret_cast<bf16x2v *>(p) = __builtin_convertvector(v, bf16x2v); }
 
-template <bool CL, typename IO, typename T>
+template <bool CL, typename IO, typename T, int E = 4>
 __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p) {
     __shared__ float s[T::TD * T::SD];
     const IO *__restrict__ in = static_cast<const IO *>(p.in);
@@ -205,59 +222,60 @@ __global__ __launch_bounds__(256) void cross_scan_vec_kernel(const CrossParams p
     tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
     const size_t L = (size_t)H * W, LR = (size_t)p.lrow;   // positions of a row; row pitch of the direction side (>= L)
-    constexpr int NIT = T::N / 4 / 256;
+    typedef typename VecOf<E>::type fv;
+    constexpr int NIT = T::N / E / 256;
     {
-        f4 v[NIT];
+        fv v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int d, h, w;
-            if (CL) dec_chn<T, 4>(tid + it * 256, d, h, w); else dec_row<T, 4>(tid + it * 256, d, h, w);
-            // 4 consecutive channels (CL) or columns per lane; sizes are multiples of 4, so a group is inside or outside as a whole
-            const int dc = min(d0 + d, CL ? D - 4 : D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, CL ? W - 1 : W - 4);
-            v[it] = CL ? ld4(in + (((size_t)b * H + hc) * W + wc) * D + dc) : ld4(in + (((size_t)b * D + dc) * H + hc) * W + wc);
+            if (CL) dec_chn<T, E>(tid + it * 256, d, h, w); else dec_row<T, E>(tid + it * 256, d, h, w);
+            // E consecutive channels (CL) or columns per lane; sizes are multiples of E, so a group is inside or outside as a whole
+            const int dc = min(d0 + d, CL ? D - E : D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, CL ? W - 1 : W - E);
+            v[it] = CL ? ldv<E>(in + (((size_t)b * H + hc) * W + wc) * D + dc) : ldv<E>(in + (((size_t)b * D + dc) * H + hc) * W + wc);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int d, h, w;
-            if (CL) dec_chn<T, 4>(tid + it * 256, d, h, w); else dec_row<T, 4>(tid + it * 256, d, h, w);
+            if (CL) dec_chn<T, E>(tid + it * 256, d, h, w); else dec_row<T, E>(tid + it * 256, d, h, w);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s[(CL ? d + e : d) * T::SD + h * T::SW + (CL ? w : w + e)] = v[it][e];
+            for (int e = 0; e < E; ++e) s[(CL ? d + e : d) * T::SD + h * T::SW + (CL ? w : w + e)] = v[it][e];
         }
     }
     __syncthreads();
-    for (int i = tid; i < T::N / 4; i += 256) {   // directions 0 and 2: runs along w
+    for (int i = tid; i < T::N / E; i += 256) {   // directions 0 and 2: runs along w
         int d, h, w;
-        dec_row<T, 4>(i, d, h, w);
+        dec_row<T, E>(i, d, h, w);
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            f4 v;
+            fv v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = s[d * T::SD + h * T::SW + w + e];
+            for (int e = 0; e < E; ++e) v[e] = s[d * T::SD + h * T::SW + w + e];
             const size_t pp = (size_t)(h0 + h) * W + w0 + w;
-            st4(out + (((size_t)b * p.nslots + 0) * D + d0 + d) * LR + pp, v);
+            stv<E>(out + (((size_t)b * p.nslots + 0) * D + d0 + d) * LR + pp, v);
             if (p.nslots == 4) {
                 IO *o2 = out + (((size_t)b * 4 + p.rmB) * D + d0 + d) * LR;
-                if (p.revB) st4(o2 + (L - 4 - pp), rev4(v)); else st4(o2 + pp, v);
+                if (p.revB) stv<E>(o2 + (L - E - pp), revv<E>(v)); else stv<E>(o2 + pp, v);
             }
         }
     }
-    for (int i = tid; i < T::N / 4; i += 256) {   // directions 1 and 3: runs along h
+    for (int i = tid; i < T::N / E; i += 256) {   // directions 1 and 3: runs along h
         int d, h, w;
-        dec_col<T, 4>(i, d, h, w);
+        dec_col<T, E>(i, d, h, w);
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            f4 v;
+            fv v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = s[d * T::SD + (h + e) * T::SW + w];
+            for (int e = 0; e < E; ++e) v[e] = s[d * T::SD + (h + e) * T::SW + w];
             const size_t q = (size_t)(w0 + w) * H + h0 + h;
-            st4(out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * LR + q, v);
+            stv<E>(out + (((size_t)b * p.nslots + p.cmA) * D + d0 + d) * LR + q, v);
             if (p.nslots == 4) {
                 IO *o3 = out + (((size_t)b * 4 + p.cmB) * D + d0 + d) * LR;
-                if (p.revB) st4(o3 + (L - 4 - q), rev4(v)); else st4(o3 + q, v);
+                if (p.revB) stv<E>(o3 + (L - E - q), revv<E>(v)); else stv<E>(o3 + q, v);
             }
         }
     }
 }
 
-template <bool CL, typename IO, typename T, bool EXTRA = false>
+template <bool CL, typename IO, typename T, bool EXTRA = false, int E = 4>
 __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams p) {
     __shared__ float s[T::TD * T::SD];
     const IO *__restrict__ in = static_cast<const IO *>(p.in);
@@ -267,29 +285,30 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
     tile_coords<T>(p, b, d0, h0, w0);
     const int tid = threadIdx.x, H = p.H, W = p.W, D = p.D;
     const size_t L = (size_t)H * W, LR = (size_t)p.lrow;   // positions of a row; row pitch of the direction side (>= L)
-    constexpr int NIT = T::N / 4 / 256;
+    typedef typename VecOf<E>::type fv;
+    constexpr int NIT = T::N / E / 256;
     const bool four = p.nslots == 4;
     const int sB = four ? 4 : p.nslots;
     {
-        f4 v[NIT], v2[NIT], v4[EXTRA ? NIT : 1];
+        fv v[NIT], v2[NIT], v4[EXTRA ? NIT : 1];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int d, h, w;
-            dec_row<T, 4>(tid + it * 256, d, h, w);
-            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - 4);
+            dec_row<T, E>(tid + it * 256, d, h, w);
+            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 1), wc = min(w0 + w, W - E);
             const size_t pp = (size_t)hc * W + wc;
-            v[it] = ld4(in + (((size_t)b * p.nslots + 0) * D + dc) * LR + pp);
+            v[it] = ldv<E>(in + (((size_t)b * p.nslots + 0) * D + dc) * LR + pp);
             const IO *i2 = in + (((size_t)b * sB + p.rmB) * D + dc) * LR;
-            v2[it] = ld4(i2 + (p.revB ? L - 4 - pp : pp));
-            if (EXTRA) v4[it] = ld4(in2 + (((size_t)b * 2 + 0) * D + dc) * LR + pp);
+            v2[it] = ldv<E>(i2 + (p.revB ? L - E - pp : pp));
+            if (EXTRA) v4[it] = ldv<E>(in2 + (((size_t)b * 2 + 0) * D + dc) * LR + pp);
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int d, h, w;
-            dec_row<T, 4>(tid + it * 256, d, h, w);
-            const f4 r = p.revB ? rev4(v2[it]) : v2[it];
+            dec_row<T, E>(tid + it * 256, d, h, w);
+            const fv r = p.revB ? revv<E>(v2[it]) : v2[it];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < E; ++e) {
                 const float a = four ? v[it][e] + r[e] : v[it][e];
                 s[d * T::SD + h * T::SW + w + e] = EXTRA ? a + v4[it][e] : a;
             }
@@ -297,26 +316,26 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
     }
     __syncthreads();
     {
-        f4 v1[NIT], v3[NIT], v5[EXTRA ? NIT : 1];
+        fv v1[NIT], v3[NIT], v5[EXTRA ? NIT : 1];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int d, h, w;
-            dec_col<T, 4>(tid + it * 256, d, h, w);
-            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - 4), wc = min(w0 + w, W - 1);
+            dec_col<T, E>(tid + it * 256, d, h, w);
+            const int dc = min(d0 + d, D - 1), hc = min(h0 + h, H - E), wc = min(w0 + w, W - 1);
             const size_t q = (size_t)wc * H + hc;
-            v1[it] = ld4(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * LR + q);
+            v1[it] = ldv<E>(in + (((size_t)b * p.nslots + p.cmA) * D + dc) * LR + q);
             const IO *i3 = in + (((size_t)b * sB + p.cmB) * D + dc) * LR;
-            v3[it] = ld4(i3 + (p.revB ? L - 4 - q : q));
-            if (EXTRA) v5[it] = ld4(in2 + (((size_t)b * 2 + 1) * D + dc) * LR + q);
+            v3[it] = ldv<E>(i3 + (p.revB ? L - E - q : q));
+            if (EXTRA) v5[it] = ldv<E>(in2 + (((size_t)b * 2 + 1) * D + dc) * LR + q);
         }
         // the reference adds in the order k0 + k2 + k1 + k3 (mamba_sys.py:448)
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int d, h, w;
-            dec_col<T, 4>(tid + it * 256, d, h, w);
-            const f4 r = p.revB ? rev4(v3[it]) : v3[it];
+            dec_col<T, E>(tid + it * 256, d, h, w);
+            const fv r = p.revB ? revv<E>(v3[it]) : v3[it];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < E; ++e) {
                 float acc = s[d * T::SD + (h + e) * T::SW + w] + v1[it][e];
                 acc = four ? acc + r[e] : acc;
                 s[d * T::SD + (h + e) * T::SW + w] = EXTRA ? acc + v5[it][e] : acc;
@@ -324,34 +343,39 @@ __global__ __launch_bounds__(256) void cross_merge_vec_kernel(const CrossParams 
         }
     }
     __syncthreads();
-    for (int i = tid; i < T::N / 4; i += 256) {
+    for (int i = tid; i < T::N / E; i += 256) {
         int d, h, w;
-        if (CL) dec_chn<T, 4>(i, d, h, w); else dec_row<T, 4>(i, d, h, w);
+        if (CL) dec_chn<T, E>(i, d, h, w); else dec_row<T, E>(i, d, h, w);
         if (d0 + d < D && h0 + h < H && w0 + w < W) {
-            f4 v;
+            fv v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = s[(CL ? d + e : d) * T::SD + h * T::SW + (CL ? w : w + e)];
-            if (CL) st4(out + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d, v);
-            else st4(out + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w, v);
+            for (int e = 0; e < E; ++e) v[e] = s[(CL ? d + e : d) * T::SD + h * T::SW + (CL ? w : w + e)];
+            if (CL) stv<E>(out + (((size_t)b * H + h0 + h) * W + w0 + w) * D + d0 + d, v);
+            else stv<E>(out + (((size_t)b * D + d0 + d) * H + h0 + h) * W + w0 + w, v);
         }
     }
 }
 
-template <typename T>
-void launch(bool merge, bool cl, bool vec, bool h, dim3 grid, hipStream_t s, const CrossParams &p) {
+// E = 0: the scalar kernels; 4 / 2: the vector kernels with that many elements per lane
+template <typename T, int E>
+void launch(bool merge, bool cl, bool h, dim3 grid, hipStream_t s, const CrossParams &p) {
     const dim3 block(256);
-#define SS2D_CROSS_LAUNCH(K)                                                                                         \
+#define SS2D_CROSS_LAUNCH(K, ...)                                                                                    \
     do {                                                                                                             \
-        if (cl) { if (h) ss2d_launch((K<true, bf16, T>), grid, block, 0, s, p); else ss2d_launch((K<true, float, T>), grid, block, 0, s, p); } \
-        else    { if (h) ss2d_launch((K<false, bf16, T>), grid, block, 0, s, p); else ss2d_launch((K<false, float, T>), grid, block, 0, s, p); } \
+        if (cl) { if (h) ss2d_launch((K<true, bf16, T, ##__VA_ARGS__>), grid, block, 0, s, p); else ss2d_launch((K<true, float, T, ##__VA_ARGS__>), grid, block, 0, s, p); } \
+        else    { if (h) ss2d_launch((K<false, bf16, T, ##__VA_ARGS__>), grid, block, 0, s, p); else ss2d_launch((K<false, float, T, ##__VA_ARGS__>), grid, block, 0, s, p); } \
     } while (0)
-    if (merge && p.in2) {   // 4 + 2 slots -> channel-first image (the one shape the backward needs)
-        if (vec) { if (h) ss2d_launch((cross_merge_vec_kernel<false, bf16, T, true>), grid, block, 0, s, p); else ss2d_launch((cross_merge_vec_kernel<false, float, T, true>), grid, block, 0, s, p); }
-        else     { if (h) ss2d_launch((cross_merge_kernel<false, bf16, T, true>), grid, block, 0, s, p); else ss2d_launch((cross_merge_kernel<false, float, T, true>), grid, block, 0, s, p); }
-        return;
+    if constexpr (E == 0) {
+        if (merge && p.in2) {   // 4 + 2 slots -> channel-first image (the one shape the backward needs)
+            if (h) ss2d_launch((cross_merge_kernel<false, bf16, T, true>), grid, block, 0, s, p); else ss2d_launch((cross_merge_kernel<false, float, T, true>), grid, block, 0, s, p);
+        } else if (merge) SS2D_CROSS_LAUNCH(cross_merge_kernel);
+        else SS2D_CROSS_LAUNCH(cross_scan_kernel);
+    } else {
+        if (merge && p.in2) {
+            if (h) ss2d_launch((cross_merge_vec_kernel<false, bf16, T, true, E>), grid, block, 0, s, p); else ss2d_launch((cross_merge_vec_kernel<false, float, T, true, E>), grid, block, 0, s, p);
+        } else if (merge) SS2D_CROSS_LAUNCH(cross_merge_vec_kernel, false, E);
+        else SS2D_CROSS_LAUNCH(cross_scan_vec_kernel, E);
     }
-    if (vec) { if (merge) SS2D_CROSS_LAUNCH(cross_merge_vec_kernel); else SS2D_CROSS_LAUNCH(cross_scan_vec_kernel); }
-    else     { if (merge) SS2D_CROSS_LAUNCH(cross_merge_kernel); else SS2D_CROSS_LAUNCH(cross_scan_kernel); }
 #undef SS2D_CROSS_LAUNCH
 }
 
@@ -376,9 +400,13 @@ int run(bool merge, bool cl, int layout, int dtype, const void *in, void *out, i
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)n);
     const bool h = dtype == SS2D_DTYPE_BF16;
-    const uintptr_t amask = h ? 7 : 15;   // 4 elements
-    const bool vec = (H % 4 == 0) && (W % 4 == 0) && (p.lrow % 4 == 0) && (!cl || D % 4 == 0) && ((((uintptr_t)in | (uintptr_t)in2 | (uintptr_t)out) & amask) == 0);
-    if (small) launch<TileSmall>(merge, cl, vec, h, grid, s, p); else launch<TileBig>(merge, cl, vec, h, grid, s, p);
+    const uintptr_t ptrs = (uintptr_t)in | (uintptr_t)in2 | (uintptr_t)out;
+    auto fits = [&](int e) {   // e elements per lane: sizes and pitch multiples of e, pointers aligned to e elements
+        return H % e == 0 && W % e == 0 && p.lrow % e == 0 && (!cl || D % e == 0) && (ptrs & (uintptr_t)(e * (h ? 2 : 4) - 1)) == 0;
+    };
+    const int e = fits(4) ? 4 : fits(2) ? 2 : 0;
+    if (small) { if (e == 4) launch<TileSmall, 4>(merge, cl, h, grid, s, p); else if (e == 2) launch<TileSmall, 2>(merge, cl, h, grid, s, p); else launch<TileSmall, 0>(merge, cl, h, grid, s, p); }
+    else { if (e == 4) launch<TileBig, 4>(merge, cl, h, grid, s, p); else if (e == 2) launch<TileBig, 2>(merge, cl, h, grid, s, p); else launch<TileBig, 0>(merge, cl, h, grid, s, p); }
     const int rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("%s: launch failed: %s", name, hipGetErrorString((hipError_t)rc));
     return rc;
