@@ -133,9 +133,29 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
         ab[k] = f4{0, 0, 0, 0};
     }
     const float invD = 1.0f / (float)D;
+    // the next row of the wave (or half-wave) is requested before this one is worked on -- see normgate_bwd_kernel; loads are
+    // never under a branch: chunks past D and rows past the end read a clamped address and are not used
+    f4 gv[K], xv[K];
+    float mu = 0.0f, rstd = 0.0f;
+    long long xoff = 0;
+    auto fetch = [&](long long r_, f4 (&g_)[K], f4 (&x_)[K], float &mu_, float &rs_, long long &xo_) {
+        const long long rc = r_ < p.rows ? r_ : p.rows - 1;
+        mu_ = p.mean_in[rc];
+        rs_ = p.rstd_in[rc];
+        xo_ = ln_row_off(p, rc);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c = lane + LW * k, cc = c < nchunk ? c : nchunk - 1;
+            g_[k] = ld4(G + rc * D + 4 * cc);
+            x_[k] = ld4(X + xo_ + co[k]);      // co[k] is already clamped to chunk 0 for c >= nchunk
+        }
+    };
+    if (wave0 < p.rows) fetch(wave0, gv, xv, mu, rstd, xoff);
     for (long long r = wave0; r < p.rows; r += nwaves) {
-        const float mu = p.mean_in[r], rstd = p.rstd_in[r];
-        const long long xoff = ln_row_off(p, r);
+        f4 gn[K], xn[K];
+        float mun, rsn;
+        long long xon;
+        fetch(r + nwaves, gn, xn, mun, rsn, xon);
         f4 nh[K], dn[K];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -144,11 +164,10 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
             nh[k] = f4{0, 0, 0, 0};
             dn[k] = f4{0, 0, 0, 0};
             if (c < nchunk) {
-                const f4 gv = ld4(G + r * D + 4 * c);
-                nh[k] = (ld4(X + xoff + co[k]) - mu) * rstd;
-                dn[k] = gv * g[k];
-                ag[k] += gv * nh[k];
-                ab[k] += gv;
+                nh[k] = (xv[k] - mu) * rstd;
+                dn[k] = gv[k] * g[k];
+                ag[k] += gv[k] * nh[k];
+                ab[k] += gv[k];
                 const f4 t = dn[k] * nh[k];
                 s1 += (dn[k].x + dn[k].y) + (dn[k].z + dn[k].w);
                 s2 += (t.x + t.y) + (t.z + t.w);
@@ -160,6 +179,11 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
             const int c = lane + LW * k;
             if (c < nchunk) st4(DX + xoff + co[k], (dn[k] - m1 - nh[k] * m2) * rstd);
         }
+#pragma unroll
+        for (int k = 0; k < K; ++k) { gv[k] = gn[k]; xv[k] = xn[k]; }
+        mu = mun;
+        rstd = rsn;
+        xoff = xon;
     }
     wg_colsum2<K, NWV, LW>(red, ag, ab, D, p.dgamma, p.dbeta);
 }
