@@ -14,6 +14,7 @@
 //   * LDS rows are 320 bytes apart (4 consecutive k rows x 64 bytes of one 32-lane half fall on 64 different banks);
 //   * the next chunk's pieces are in flight (registers) while the current one is multiplied; one barrier per chunk;
 //   * the 96 x 128 result goes through LDS once more so that the stores are whole 256-byte rows.
+#include <type_traits>
 #include "ss2d_common.h"
 #include "../../include/ss2d.h"
 
@@ -61,9 +62,15 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
     // this thread's pieces of a chunk (row / column fixed over the chunks)
     constexpr int XPB = V16 ? 16 : 8, XPR = 2 * BN / XPB, NXP = KC * XPR / 256, XE = XPB / 2;   // piece bytes, pieces per row, per thread
     typedef unsigned xpiece_t __attribute__((ext_vector_type(V16 ? 4 : 2)));
-    xpiece_t xr[NXP];
-    u32x4 wr[NWP];
-    auto load_chunk = [&](int c) {
+    // TWO chunks in flight in registers (set = stage = chunk parity): a workgroup of the long contractions (x_proj forward:
+    // 12 / 24 chunks at the 14 x 14 / 7 x 7 stages) walked them one memory round trip at a time
+    constexpr bool DEEP = KC == 64;        // the short contractions (KC = 32: 1-4 chunks) keep one chunk ahead and their occupancy
+    xpiece_t xr[DEEP ? 2 : 1][NXP];
+    u32x4 wr[DEEP ? 2 : 1][NWP];
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    auto load_chunk = [&](auto set, int c) {                 // a chunk past K reads as zeros
+        constexpr int S = DEEP ? decltype(set)::value : 0;
         // never a guarded load: the address is clamped to element 0 and the value masked
 #pragma unroll
         for (int j = 0; j < NXP; ++j) {
@@ -71,7 +78,7 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
             const int k = c * KC + row, col = l0 + pc * XE;
             const bool ok = k < p.K && col < L;
             const xpiece_t v = *reinterpret_cast<const xpiece_t *>(Xg + (ok ? (size_t)k * L + col : 0));
-            xr[j] = v & (ok ? ~0u : 0u);
+            xr[S][j] = v & (ok ? ~0u : 0u);
         }
 #pragma unroll
         for (int j = 0; j < NWP; ++j) {
@@ -79,20 +86,21 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
             const int k = c * KC + pc * 8;
             const bool ok = row < BM && m0 + row < p.M && k < p.ldw;
             const u32x4 v = *reinterpret_cast<const u32x4 *>(Wg + (ok ? (size_t)row * p.ldw + k : 0));
-            wr[j] = v & (ok ? ~0u : 0u);
+            wr[S][j] = v & (ok ? ~0u : 0u);
         }
     };
-    auto put_chunk = [&](int s) {
-        unsigned char *xs = lds + s * STAGE, *ws = xs + XBYTES;
+    auto put_chunk = [&](auto set, int stage) {
+        constexpr int S = DEEP ? decltype(set)::value : 0;
+        unsigned char *xs = lds + stage * STAGE, *ws = xs + XBYTES;
 #pragma unroll
         for (int j = 0; j < NXP; ++j) {
             const int id = j * 256 + tid, row = id / XPR, pc = id - row * XPR;
-            *reinterpret_cast<xpiece_t *>(xs + row * XROW + pc * XPB) = xr[j];
+            *reinterpret_cast<xpiece_t *>(xs + row * XROW + pc * XPB) = xr[S][j];
         }
 #pragma unroll
         for (int j = 0; j < NWP; ++j) {
             const int id = j * 256 + tid, row = id / WPR, pc = id - row * WPR;
-            if (BM * WPR % 256 == 0 || row < BM) *reinterpret_cast<u32x4 *>(ws + row * WROW + pc * 16) = wr[j];
+            if (BM * WPR % 256 == 0 || row < BM) *reinterpret_cast<u32x4 *>(ws + row * WROW + pc * 16) = wr[S][j];
         }
     };
 
@@ -108,13 +116,8 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
     const int xoff = (8 * (gq >> 1) + q) * XROW + (32 * wave + 16 * (gq & 1) + 4 * pp) * 2;
     const int woff = l32 * WROW + 16 * half;
 
-    load_chunk(0);
-    for (int c = 0; c < nchunks; ++c) {
-        const int s = c & 1;
-        put_chunk(s);                                     // stage s was last read two chunks ago, behind the previous barrier
-        load_chunk(c + 1 < nchunks ? c + 1 : c);          // in flight during the products (the last one is a harmless repeat)
-        __syncthreads();
-        const unsigned char *xs = lds + s * STAGE, *ws = xs + XBYTES;
+    auto products = [&](int stage) {
+        const unsigned char *xs = lds + stage * STAGE, *ws = xs + XBYTES;
 #pragma unroll
         for (int ks = 0; ks < KC / 16; ++ks) {
             typedef s16x4 __attribute__((address_space(3))) *lp;
@@ -126,6 +129,31 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
                 const bf16x8 af = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(ws + mt * 32 * WROW + woff + 32 * ks));
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[mt], 0, 0, 0);
             }
+        }
+    };
+    if constexpr (DEEP) {
+        load_chunk(S0, 0);
+        load_chunk(S1, 1);
+        // two chunks per trip, nothing under a branch (an odd count ends with a chunk of zeros); a stage was last read two
+        // chunks ago, behind the previous barrier
+        for (int c = 0; c < nchunks; c += 2) {
+            put_chunk(S0, 0);
+            load_chunk(S0, c + 2);
+            __syncthreads();
+            products(0);
+            put_chunk(S1, 1);
+            load_chunk(S1, c + 3);
+            __syncthreads();
+            products(1);
+        }
+    } else {
+        load_chunk(S0, 0);
+        for (int c = 0; c < nchunks; ++c) {
+            const int st = c & 1;
+            put_chunk(S0, st);                                // stage st was last read two chunks ago, behind the previous barrier
+            load_chunk(S0, c + 1);                            // in flight during the products (past K: zeros, never used)
+            __syncthreads();
+            products(st);
         }
     }
     __syncthreads();
