@@ -643,3 +643,29 @@ def test_layernorm_merge_gather(B, H, W, C, dtype):
     assert y.shape == (B, h2, w2, 4 * C)
     assert rel_l2(y.detach().float().cpu(), yr.detach()) < tol and rel_l2(xd.grad.float().cpu(), xr.grad) < tol
     assert rel_l2(ln.weight.grad.cpu(), ref.weight.grad) < tol and rel_l2(ln.bias.grad.cpu(), ref.bias.grad) < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch_embed_as_linear_equals_conv(dtype, monkeypatch):
+    """PatchEmbed2D (mamba_sys.py:166-188): the stride-4 4x4 convolution as a Linear over gathered patches against the
+    convolution itself (SS2D_PATCH_CONV=1): output, weight and bias gradients."""
+    from mamba_unet_amd.vssm import PatchEmbed2D
+    torch.manual_seed(3)
+    m = PatchEmbed2D(4, 3, 96, torch.nn.LayerNorm).cuda()
+    x = torch.randn(6, 3, 224, 224, device="cuda")
+    g = torch.randn(6, 56, 56, 96, device="cuda")
+    res = {}
+    for conv in (True, False):
+        if conv:
+            monkeypatch.setenv("SS2D_PATCH_CONV", "1")
+        else:
+            monkeypatch.delenv("SS2D_PATCH_CONV", raising=False)
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            y = m(x)
+        y.float().backward(g)
+        res[conv] = (y.detach().float(), m.proj.weight.grad.clone(), m.proj.bias.grad.clone(), m.norm.weight.grad.clone())
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    for a, b in zip(res[False], res[True]):
+        assert a.shape == b.shape and rel_l2(a.cpu(), b.cpu()) < tol
