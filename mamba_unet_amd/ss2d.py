@@ -145,8 +145,8 @@ class SS2D(nn.Module):
         # (plain views / one fused kernel; no index tensor, so the step stays HIP-graph capturable)
         slots = GradSlots() if (x.is_cuda and x.requires_grad and not os.environ.get("SS2D_NO_GATHER6")) else None     # du and d(xs2) meet in one gather (backward)
         core = x.dtype == torch.float32 or (self.bf16_scan_io and x.dtype == torch.bfloat16)
-        if core and L % 8 and x.is_cuda and not os.environ.get("SS2D_NO_ROW_PAD"):
-            # 7 x 7 (L = 49): rows padded to a multiple of 8 and zero in the pad, so that x_proj, dt_proj and the scan keep
+        if core and L % 4 and x.is_cuda and not os.environ.get("SS2D_NO_ROW_PAD"):
+            # 7 x 7 (L = 49; any L that is not a multiple of 4): rows padded to a multiple of 8 and zero in the pad, so that x_proj, dt_proj and the scan keep
             # their aligned kernels.  u = 0 there: a reversed scan (which meets the pad first) stays at state 0 until the
             # first real position, a forward scan reaches the pad behind the last one; x_dbl and dy are 0 in the pad, so no
             # parameter gradient sees it, and the gathers read the H*W real positions only.
@@ -214,6 +214,27 @@ class SS2D(nn.Module):
         return out
 
 
+class _ResidualScaled(torch.autograd.Function):
+    """input + y * scale (scale per sample): the residual connection with stochastic depth as one pass each way.  Autograd's
+    backward of addcmul is a multiply in the residual stream's dtype followed by a cast to y's; here the gradient of y is
+    written in y's dtype by the multiply itself, and the residual gradient passes through untouched."""
+
+    @staticmethod
+    def forward(ctx, input, y, scale):
+        ctx.save_for_backward(scale)
+        ctx.y_dtype = y.dtype
+        return torch.addcmul(input, y, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        (scale,) = ctx.saved_tensors
+        gy = None
+        if ctx.needs_input_grad[1]:
+            gy = torch.empty(g.shape, device=g.device, dtype=ctx.y_dtype)
+            torch.mul(g, scale, out=gy)
+        return (g if ctx.needs_input_grad[0] else None), gy, None
+
+
 class VSSBlock(nn.Module):
     """x + DropPath(SS2D(LayerNorm(x)))  (mamba_sys.py:568-585)."""
 
@@ -233,7 +254,7 @@ class VSSBlock(nn.Module):
             # of (y*mask)/keep): input + y * mask / keep
             keep = 1.0 - dp.drop_prob
             mask = y.new_empty((y.shape[0],) + (1,) * (y.dim() - 1)).bernoulli_(keep)
-            return torch.addcmul(input, y, (mask / keep).to(input.dtype))
+            return _ResidualScaled.apply(input, y, (mask / keep).to(input.dtype))
         return input + dp(y)
 
 
