@@ -136,13 +136,13 @@ def stream():
 
 _ARENA = {}                 # device -> [zero-filled fp32 chunk, floats handed out, capture epoch]
 _ARENA_EPOCH = [0, False]   # bumped whenever the stream's capture state changes between two requests
-_ARENA_FLOATS = 1 << 20     # 4 MB per chunk
-_ARENA_MAX_REQ = 1 << 17    # requests above 512 KB get a buffer (and a fill) of their own
+_ARENA_FLOATS = 1 << 23     # 32 MB per chunk: a training step of MambaUNet zero-fills 19 M gradient floats -- three chunks
+_ARENA_MAX_REQ = 1 << 21    # requests above 8 MB get a buffer (and a fill) of their own
 _ARENA_LOCK = None
 
 
 def zeros_flat(device, n):
-    """n fp32 zeros (1-D).  Small requests are carved out of a zero-filled 4 MB chunk per device, so the ~100 accumulated
+    """n fp32 zeros (1-D).  Small requests are carved out of a zero-filled 32 MB chunk per device, so the ~100 accumulated
     gradient buffers of a training step (dgamma, dbeta, dA, dD, bias and small weight gradients: float-atomic targets)
     cost a handful of fill launches instead of one each.  A chunk is never reused -- its pieces must be zero -- and
     lives as long as any piece does; pieces start on 256-byte boundaries.  A chunk filled outside a HIP-graph capture is
