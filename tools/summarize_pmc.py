@@ -48,6 +48,7 @@ def main():
                     a[0] += float(r["Counter_Value"])
                     a[1] += 1
     dur = collections.defaultdict(lambda: [0.0, 0])
+    seqs = collections.defaultdict(list)       # (start, duration) per dispatch: the timed steps are the last ones of the run
     for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
         with open(f) as fh:
             for r in csv.DictReader(fh):
@@ -55,6 +56,7 @@ def main():
                 if k:
                     dur[k][0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
                     dur[k][1] += 1
+                    seqs[k].append((float(r["Start_Timestamp"]), float(r["End_Timestamp"]) - float(r["Start_Timestamp"])))
     avg = {kc: s / n for kc, (s, n) in acc.items()}
     print(f"{'kernel':18s} {'counter':26s} {'avg per dispatch':>20s} {'dispatches':>10s}")
     for (k, c), (s, n) in sorted(acc.items()):
@@ -65,6 +67,8 @@ def main():
         if k in dur:
             dur_us[k] = dur[k][0] / dur[k][1] / 1e3
             print(f"{k}: average duration under --kernel-trace {dur_us[k]:.1f} us over {dur[k][1]} dispatches")
+            last = [d for _, d in sorted(seqs[k])][-20:]
+            print(f"{k}: the last {len(last)} dispatches (the timed steps; the run starts with bench.py's pre-warm) average {sum(last) / len(last) / 1e3:.1f} us")
         fs, ws = avg.get((k, "FETCH_SIZE")), avg.get((k, "WRITE_SIZE"))
         if fs is not None and ws is not None:
             rd, wr = 2 * fs * 1024, ws * 1024
