@@ -83,7 +83,7 @@ def run(args, rank, world, local, dist):
     torch.manual_seed(1337)                       # train_fully_supervised_2D_VIM.py:243-246
     if args.mode == "semi" and args.model1 == "unet":     # train_Semi_Mamba_UNet.py:302-303 (default model1) + :325 (model2)
         from mamba_unet_amd.unet import UNet
-        nets = [UNet(in_chns=1, class_num=args.classes).to(dev), MambaUnet(img_size=args.size, num_classes=args.classes).to(dev)]
+        nets = [UNet(in_chns=1, class_num=args.classes).to(dev).native_layout(), MambaUnet(img_size=args.size, num_classes=args.classes).to(dev)]
     else:
         nets = [MambaUnet(img_size=args.size, num_classes=args.classes).to(dev) for _ in range(2 if args.mode == "semi" else 1)]
     n_params = sum(p.numel() for p in nets[-1].parameters())

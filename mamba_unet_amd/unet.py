@@ -96,11 +96,17 @@ class UNet(nn.Module):
     # first GPU forward); the logits are returned NCHW-contiguous as the reference's are.
     channels_last = True
 
+    def native_layout(self):
+        """Convert the parameters to channel-last now (call it before wrapping the model in DDP, whose buckets record the
+        gradients' strides); forward() does it at the first GPU batch otherwise.  Returns self."""
+        if self.channels_last and not getattr(self, "_nhwc", False):
+            self.to(memory_format=torch.channels_last)
+            self._nhwc = True
+        return self
+
     def forward(self, x):
         if x.is_cuda and self.channels_last:
-            if not getattr(self, "_nhwc", False):
-                self.to(memory_format=torch.channels_last)
-                self._nhwc = True
+            self.native_layout()
             x = x.contiguous(memory_format=torch.channels_last)
             return self.decoder(self.encoder(x)).contiguous()
         return self.decoder(self.encoder(x))
