@@ -254,7 +254,8 @@ class VSSBlock(nn.Module):
             # of (y*mask)/keep): input + y * mask / keep
             keep = 1.0 - dp.drop_prob
             mask = y.new_empty((y.shape[0],) + (1,) * (y.dim() - 1)).bernoulli_(keep)
-            return _ResidualScaled.apply(input, y, (mask / keep).to(input.dtype))
+            # the scale in the residual stream's precision (1 / keep rounded to bf16 first would bias the branch by up to 0.4 %)
+            return _ResidualScaled.apply(input, y, mask.to(input.dtype).div_(keep))
         return input + dp(y)
 
 
