@@ -165,3 +165,35 @@ def test_graphed_supervised_step_matches_eager(bf16):
         lg = float(gstep(gstep.images, gstep.labels, warm + k))
         le = float(supervised_step(net2, opt2, images, labels, 4, warm + k, 10000, autocast_bf16=bf16))
         assert abs(lg - le) <= (1e-3 if bf16 else 1e-6) * abs(le), (k, lg, le)
+
+
+def test_unet_channel_last_on_gpu_equals_cpu_forward_and_grads():
+    """UNet (model1 of configs[3]) runs channel-last on the GPU: logits NCHW-contiguous, forward and every parameter
+    gradient equal the plain NCHW CPU run of the same weights (fp32, eval-mode dropout off via p=0 input-independent BN in
+    train mode is kept: batch statistics are layout-independent)."""
+    from mamba_unet_amd.unet import UNet
+    torch.manual_seed(5)
+    ref = UNet(in_chns=1, class_num=4).train()
+    for m in ref.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net = UNet(in_chns=1, class_num=4)
+    net.load_state_dict(ref.state_dict())
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    net = net.cuda().train().native_layout()
+    x = torch.randn(3, 1, 64, 64)
+    g = torch.randn(3, 4, 64, 64)
+    yr = ref(x)
+    yr.backward(g)
+    y = net(x.cuda())
+    assert y.is_contiguous() and y.shape == yr.shape
+    y.backward(g.cuda())
+    assert rel_l2(y.detach().cpu(), yr.detach()) < 1e-4
+    keys = [k for k, _ in ref.named_parameters()]
+    assert keys == [k for k, _ in net.named_parameters()]
+    for (k, pr), (_, p) in zip(ref.named_parameters(), net.named_parameters()):
+        # a convolution bias in front of a BatchNorm has a zero gradient: both sides hold rounding noise there
+        err = (p.grad.cpu() - pr.grad).norm().item()
+        assert p.grad.shape == pr.grad.shape and (err < 2e-3 * pr.grad.norm().item() or err < 1e-3), k
