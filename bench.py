@@ -12,6 +12,11 @@ every rank runs its own batch (weak scaling); value = bytes of all ranks / max-o
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+A bare `python bench.py --gpus N` (no RANK / WORLD_SIZE in the environment) is the launcher: before any GPU call it
+starts N fresh rank processes through torch.distributed.run (mamba_unet_amd/launch.py), relays rank 0's line and
+leaves with their exit status; it refuses to run when fewer than N GPUs are visible.  `--dry gloo` runs the same
+launcher / rank plumbing on CPU (no GPU, no kernels): the CPU test suite uses it.
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -49,7 +54,9 @@ def scan_sources_hash():
 
 def load_pmc():
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_pmc.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_pmc.json")),
+                   key=lambda f: int(re.search(r"r(\d+)", os.path.basename(os.path.dirname(f))).group(1)))
     if not files:
         return None
     with open(files[-1]) as fh:
@@ -69,12 +76,23 @@ def algorithmic_bytes(batch):
 
 PREWARM_STEPS = 25      # untimed steps ahead of the warm-up (clock ramp), see main()
 
+# MambaUNet legs appended to the line: bench_model.py arguments + algorithmic scan MB per slice fwd+bwd (SURVEY.md 8d;
+# forward only = 732/1965 of it; the 512x512 network has 5.22x the tokens of the 224x224 one)
+_T = ["--dtype", "bf16", "--batch", "24"]
+MODEL_LEGS = {
+    "train224": (["--mode", "train", *_T, "--steps", "20", "--warmup", "5"], 584.2),                      # configs[2]
+    "infer224": (["--mode", "infer", *_T, "--steps", "20", "--warmup", "5"], 584.2 * 732.2 / 1965.5),
+    "train512": (["--mode", "train", *_T, "--size", "512", "--classes", "9", "--steps", "10", "--warmup", "3"],
+                 584.2 * (512 * 512) / (224 * 224)),                                                     # configs[4]
+    "semi224": (["--mode", "semi", *_T, "--steps", "10", "--warmup", "3"], None),                          # configs[3]
+}
+
 
 def cpu_baseline():
     """The reference's CPU path (sequential selective_scan_ref in PyTorch, restated in oracle/) timed
     on this host: forward + autograd backward on CPU_SLICES slices of the same workload."""
-    from oracle.selective_scan_ref import selective_scan_ref
-    from oracle.ss2d_ref import make_scan_inputs
+    from oracle.selective_scan_ref import selective_scan_ref      # the checker: this leg and the parity block only
+    from mamba_unet_amd.synthetic import make_scan_inputs
     cores = min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     nb = CPU_SLICES
@@ -101,20 +119,36 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--atomic-dbc", action="store_true", help="dB/dC through float atomics (no workspace): the round-1 form")
-    ap.add_argument("--no-model", action="store_true", help="skip the MambaUNet training-step leg (second half of BASELINE.json's metric)")
+    ap.add_argument("--no-model", action="store_true", help="skip the MambaUNet legs (second half of BASELINE.json's metric)")
+    ap.add_argument("--model-legs", default="train224,infer224,train512,semi224",
+                    help="comma list of the MambaUNet legs appended outside the timed region (see MODEL_LEGS)")
+    ap.add_argument("--dry", choices=["gloo"], default=None, help="CPU dry run of the launcher / rank plumbing (no GPU, no kernels)")
     args = ap.parse_args()
+
+    # ---- launcher: `--gpus N > 1` given to a bare process -> N fresh ranks, started before this process touches the GPU
+    from mamba_unet_amd import launch
+    launch.maybe_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:], dry_backend=args.dry)
+    if args.dry:
+        rec = launch.dry_rank("SS2D selective-scan fwd+bwd achieved HBM GB/s (algorithmic bytes / time)")
+        if rec["rank"] == 0:
+            print(json.dumps(rec))
+        return
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: note: --gpus {args.gpus} but the launcher's WORLD_SIZE is {world}; reporting n_gpus={world}", file=sys.stderr)
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # a rank that dies leaves the others in a collective: a bounded timeout turns that into an error, not a hang
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=5))
 
     from mamba_unet_amd import _lib
-    from oracle.ss2d_ref import make_scan_inputs
+    from mamba_unet_amd.synthetic import make_scan_inputs
     lib = _lib.load()
     dev = torch.device("cuda", local)
 
@@ -194,22 +228,39 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * (fb + bb) / (elapsed / args.steps) / 1e9
 
-    # ---- second half of BASELINE.json's metric: MambaUNet train slices/s at 224x224 (configs[2]: batch 24 per GPU, bf16,
-    # DDP over RCCL when N > 1), outside the timed region of the headline value; same barrier + max-over-ranks timing
-    model = None
+    # ---- second half of BASELINE.json's metric: MambaUNet slices/s (configs[2], [3], [4] + the eval forward), batch 24
+    # per GPU, bf16, DDP over RCCL when N > 1; outside the timed region of the headline value, same barrier +
+    # max-over-ranks timing.  A leg that fails is reported, not hidden, and must fail on EVERY rank together: the ranks
+    # agree on a success flag before the next leg enters its collectives.
+    models = {}
     if not args.no_model:
         import bench_model
-        margs = bench_model.parser().parse_args(["--mode", "train", "--dtype", "bf16", "--steps", "20", "--warmup", "5"])
-        try:
-            model = bench_model.run(margs, rank, world, local, dist)
-        except Exception as e:      # the headline line must survive a failure of the secondary leg; it is reported, not hidden
-            model = {"error": f"{type(e).__name__}: {e}"[:300]} if rank == 0 else None
-        if model is not None and "error" not in model:
-            # SURVEY.md 8(d) "whole-model algorithmic scan bytes": 584.2 MB per slice fwd+bwd in fp32, half of it with bf16 I/O
-            scan_bytes = 0.5 * 584.2e6 * margs.batch
-            model = {k: model[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "peak_mem_GB", "valid")}
-            model["scan_algorithmic_GBs_per_gpu"] = round(scan_bytes / (model["ms_per_step"] * 1e-3) / 1e9, 1)
-            model["frac_of_hbm_peak_scan_bytes_only"] = round(model["scan_algorithmic_GBs_per_gpu"] / HBM_PEAK_GBS, 4)
+        for leg in [x for x in args.model_legs.split(",") if x]:
+            margv, scan_mb_per_slice = MODEL_LEGS[leg]
+            margs = bench_model.parser().parse_args(margv)
+            rec, ok = None, 1
+            try:
+                rec = bench_model.run(margs, rank, world, local, dist)
+            except Exception as e:
+                rec, ok = {"error": f"rank {rank}: {type(e).__name__}: {e}"[:300]}, 0
+            if dist is not None:
+                flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if ok:
+                        rec = {"error": "another rank failed in this leg"}
+                    elif rank != 0:
+                        print(f"bench.py: model leg {leg}: {rec['error']}", file=sys.stderr)
+            if rank == 0 and rec is not None and "error" not in rec:
+                rec = {k: rec[k] for k in ("metric", "value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "dtype", "config", "peak_mem_GB", "valid")}
+                if scan_mb_per_slice:
+                    # SURVEY.md 8(d) "whole-model algorithmic scan bytes" per slice (fp32 figure; bf16 I/O moves half of it)
+                    gbs = 0.5 * scan_mb_per_slice * 1e6 * margs.batch / (rec["ms_per_step"] * 1e-3) / 1e9
+                    rec["scan_algorithmic_GBs_per_gpu"] = round(gbs, 1)
+                    rec["frac_of_hbm_peak_scan_bytes_only"] = round(gbs / HBM_PEAK_GBS, 4)
+            models[leg] = rec
+            torch.cuda.empty_cache()
+    model = models.get("train224")
 
     if rank == 0:
         # parity spot check of what was just timed (slice 0) + CPU baseline, N=1 only
@@ -248,12 +299,15 @@ def main():
                          "traffic_source": (pmc["file"] + (" (kernel sources unchanged since)" if pmc["sources_match"] else
                                                             " (STALE: kernel sources changed since)")) if pmc else None,
                          "algorithmic_bytes_per_launch": dominant_bytes, "avg_launch_us": round(dominant_us, 2),
-                         "limiter": "valu (see roofline_valu): HBM traffic is ~1.1x the algorithmic bytes, the vector ALU is what is busy"},
+                         "limiter": "valu (see roofline_valu): the vector ALU is what is busy; measured HBM traffic / algorithmic bytes = "
+                                    + (f"{traffic / dominant_bytes:.2f}x" if traffic else "not measured")},
             "roofline_valu": valu, "rccl_world_seen": rccl_world_seen,
             "frac_of_hbm_peak_fwd_bwd": round(value / world / HBM_PEAK_GBS, 4),
             "kernels_us": {"scan_fwd": round(fwd_us, 2), "scan_bwd": round(bwd_us, 2),
                            "fwd_GBs": round(fb / fwd_us / 1e3, 1), "bwd_GBs": round(bb / bwd_us / 1e3, 1)},
             "cpu_baseline": cpu, "parity_rel_l2_vs_cpu_oracle": parity, "mambaunet_train": model,
+            "mambaunet_infer_224": models.get("infer224"), "mambaunet_train_512": models.get("train512"),
+            "semi_224": models.get("semi224"),
         }
         print(json.dumps(line))
     if dist is not None:

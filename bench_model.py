@@ -48,19 +48,29 @@ def parser():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--dry", choices=["gloo"], default=None, help="CPU dry run of the launcher / rank plumbing (no GPU, no kernels)")
     return ap
 
 
 def main():
     args = parser().parse_args()
+    # `--gpus N > 1` given to a bare process: become the launcher of N fresh ranks before any GPU call (launch.py)
+    from mamba_unet_amd import launch
+    launch.maybe_launch(os.path.abspath(__file__), args.gpus, sys.argv[1:], dry_backend=args.dry)
+    if args.dry:
+        rec = launch.dry_rank(f"MambaUNet {args.mode} slices/s @{args.size}x{args.size}")
+        if rec["rank"] == 0:
+            print(json.dumps(rec))
+        return
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(minutes=5))
     line = run(args, rank, world, local, dist)
     if rank == 0:
         print(json.dumps(line))
@@ -72,6 +82,7 @@ def run(args, rank, world, local, dist):
     """One measurement (bench.py calls this too, for the model-level half of BASELINE.json's metric).  Returns the JSON
     record on rank 0, None elsewhere.  `dist` is the initialised torch.distributed module or None."""
     dev = torch.device("cuda", local)
+    torch.cuda.reset_peak_memory_stats(dev)
     from mamba_unet_amd import MambaUnet
     from mamba_unet_amd.dist import wrap_ddp
     from mamba_unet_amd.train import GraphedSupervisedStep, WeightCopies, make_sgd, semi_step, supervised_step
@@ -149,6 +160,9 @@ def run(args, rank, world, local, dist):
 
     from mamba_unet_amd import SS2D as _SS2D
     _SS2D.bf16_scan_io, _SS2D.fused_directions = False, True          # class-wide switches back to their defaults
+    cp = locals().get("copies")
+    for c in (cp if isinstance(cp, list) else [cp] if cp is not None else []):
+        c.close()                                                      # bench.py runs several legs in one process
     if rank == 0:
         if not finite:
             print("bench_model.py: WARNING: the last step's output is not finite -- this run is not a valid measurement", file=sys.stderr)

@@ -68,10 +68,16 @@ def all_reduce_sum(x: torch.Tensor) -> torch.Tensor:
     return _AllReduceSum.apply(x)
 
 
-def wrap_ddp(model: torch.nn.Module, local_rank: int | None = None):
+def wrap_ddp(model: torch.nn.Module, local_rank: int | None = None, force: bool = False):
     """DistributedDataParallel with the settings SURVEY.md 5 derives: every parameter gets a gradient each
-    step (find_unused_parameters=False, static_graph=True), buckets are views (one less copy of the 76.5 MB gradient)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    step (find_unused_parameters=False, static_graph=True), buckets are views (one less copy of the 76.5 MB gradient).
+    A world of one rank returns the bare model unless `force` (the world-1 RCCL test wraps the real network to run
+    DDP's hooks, bucket views and static-graph bookkeeping against this package's autograd nodes on one GPU)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        if force:
+            raise RuntimeError("wrap_ddp(force=True) needs an initialised process group")
+        return model
+    if dist.get_world_size() == 1 and not force:
         return model
     from torch.nn.parallel import DistributedDataParallel as DDP
     ids = [local_rank] if (local_rank is not None and next(model.parameters()).is_cuda) else None

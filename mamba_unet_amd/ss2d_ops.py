@@ -427,8 +427,10 @@ class _Linear(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.w_dtype, ctx.b_dtype = weight.dtype, None if bias is None else bias.dtype
         y = None
-        if _token_gemm_pays(x.numel() // x.shape[-1], w.shape[0], w.shape[1]):           # bf16: own MFMA kernel
-            y = token_gemm(x, w, False) if b is None else token_gemm_cat(x, None, w, bias if bias.dtype == torch.float32 else None)
+        # bf16: own MFMA kernel.  Its bias input is fp32 (added before the rounding): a bias of any other dtype (a module
+        # converted with .bfloat16(), no autocast) goes to the library below -- never silently without its bias
+        if _token_gemm_pays(x.numel() // x.shape[-1], w.shape[0], w.shape[1]) and (bias is None or bias.dtype == torch.float32):
+            y = token_gemm(x, w, False) if bias is None else token_gemm_cat(x, None, w, bias)
         if y is not None:
             return y
         with torch.autocast("cuda", enabled=False):

@@ -276,12 +276,18 @@ def semi_loss(o1, o2, labels, labeled_bs, n_classes, consistency_weight):
     labelled slices, Dice of each network's softmax against the OTHER network's argmax on the unlabelled slices
     (argmax of the softmax = argmax of the logits), and ConstraLoss of the logits, counted once for each network."""
     lab = labels[:labeled_bs]
-    ce1, d1 = ce_dice_loss(o1[:labeled_bs], lab, n_classes)
-    ce2, d2 = ce_dice_loss(o2[:labeled_bs], lab, n_classes)
     pseudo1 = torch.argmax(o1[labeled_bs:].detach(), dim=1)
     pseudo2 = torch.argmax(o2[labeled_bs:].detach(), dim=1)
-    _, ps1 = ce_dice_loss(o1[labeled_bs:], pseudo2, n_classes)
-    _, ps2 = ce_dice_loss(o2[labeled_bs:], pseudo1, n_classes)
+    C = n_classes
+    # the four statistics vectors travel in ONE all-reduce (forward) and one in backward instead of four each; the
+    # cross entropies are means over the rank's own pixels (DDP's gradient average makes them global), taken before it
+    local = torch.stack([seg_loss_stats(o1[:labeled_bs], lab, C), seg_loss_stats(o2[:labeled_bs], lab, C),
+                         seg_loss_stats(o1[labeled_bs:], pseudo2, C), seg_loss_stats(o2[labeled_bs:], pseudo1, C)])
+    n_lab = o1[:labeled_bs].numel() // C
+    ce1, ce2 = local[0, 3 * C] / n_lab, local[1, 3 * C] / n_lab
+    stats = all_reduce_sum(local)
+    inter, ysum, zsum = stats[:, :C], stats[:, C:2 * C], stats[:, 2 * C:3 * C]
+    d1, d2, ps1, ps2 = (1.0 - (2 * inter + 1e-5) / (zsum + ysum + 1e-5)).mean(dim=1)
     con = constra_loss(o1.float(), o2.float())
     return (0.5 * (ce1 + d1) + consistency_weight * ps1 + 0.5 * con) + (0.5 * (ce2 + d2) + consistency_weight * ps2 + 0.5 * con)
 

@@ -12,7 +12,6 @@ oracle.selective_scan_ref injected as `selective_scan_fn`.
 """
 from __future__ import annotations
 
-import math
 
 import numpy as np
 import torch
@@ -120,18 +119,6 @@ def ss2d_forward_ref(x, sd: dict, scan_fn=selective_scan_ref, capture: dict | No
 
 
 # ----------------------------------------------------------------------------- synthetic inputs
-def make_scan_inputs(batch, dim, L, dstate=16, ngroups=4, seed=0, integer_A=True, dtype=torch.float32):
-    """Inputs distributed like the SS2D call site (init statics mamba_sys.py:340-394)."""
-    g = torch.Generator().manual_seed(seed)
-    u = torch.randn(batch, dim, L, generator=g, dtype=dtype)
-    delta = 0.5 * torch.randn(batch, dim, L, generator=g, dtype=dtype)
-    Bm = torch.randn(batch, ngroups, dstate, L, generator=g, dtype=dtype)
-    Cm = torch.randn(batch, ngroups, dstate, L, generator=g, dtype=dtype)
-    if integer_A:
-        A = -torch.arange(1, dstate + 1, dtype=torch.float32).repeat(dim, 1)        # A_log_init
-    else:
-        A = -torch.exp(torch.randn(dim, dstate, generator=g))
-    D = torch.ones(dim) if integer_A else torch.randn(dim, generator=g)
-    dt = torch.exp(torch.rand(dim, generator=g) * (math.log(0.1) - math.log(0.001)) + math.log(0.001)).clamp(min=1e-4)
-    delta_bias = dt + torch.log(-torch.expm1(-dt))                                   # dt_init :354-361
-    return dict(u=u, delta=delta, A=A, B=Bm, C=Cm, D=D, delta_bias=delta_bias)
+# The generator is not checker logic: it lives in the neutral mamba_unet_amd.synthetic (bench.py and tools/ use it
+# without importing this package) and is re-exported here for the tests that already import it from the oracle.
+from mamba_unet_amd.synthetic import make_scan_inputs  # noqa: E402,F401

@@ -596,6 +596,30 @@ def test_linear_function_bf16():
     assert rel_l2(xd.grad.float().cpu(), xr.grad) < 4e-3 and rel_l2(wd.grad.float().cpu(), wr.grad) < 4e-3
 
 
+@pytest.mark.parametrize("bias_dtype,autocast", [(torch.bfloat16, False), (torch.float32, True), (torch.float32, False)])
+def test_linear_function_keeps_its_bias(bias_dtype, autocast):
+    """A biased Linear through ss2d_ops.linear: a pure-bf16 module (model.bfloat16(), no autocast: bf16 bias) must not lose
+    its bias on the way to the own kernel (whose bias input is fp32); fp32 master parameters under autocast take the own
+    kernel with the bias; an fp32 module without autocast goes to the library.  All against F.linear in fp64."""
+    from mamba_unet_amd import ss2d_ops
+    gen = torch.Generator().manual_seed(12)
+    pdt = bias_dtype
+    x = torch.randn(2, 28, 28, 96, generator=gen).to(torch.bfloat16 if (autocast or pdt == torch.bfloat16) else torch.float32)
+    w = (torch.randn(192, 96, generator=gen) * 0.1).to(pdt)
+    b = (torch.randn(192, generator=gen) * 3.0).to(pdt)               # large against x W^T: a dropped bias cannot hide
+    g = torch.randn(2, 28, 28, 192, generator=gen).to(x.dtype)
+    xd, wd, bd = (t.cuda().requires_grad_(True) for t in (x, w, b))
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y = ss2d_ops.linear(xd, wd, bd)
+    y.backward(g.cuda().to(y.dtype))
+    wq = w.to(torch.bfloat16) if autocast else w
+    want = x.double() @ wq.double().t() + b.double()
+    tol = 1e-5 if y.dtype == torch.float32 else 6e-3
+    assert rel_l2(y.detach().float().cpu(), want) < tol
+    assert bd.grad is not None and rel_l2(bd.grad.float().cpu(), g.double().sum((0, 1, 2))) < tol
+    assert rel_l2(xd.grad.float().cpu(), g.double() @ wq.double()) < tol
+
+
 @pytest.mark.parametrize("dtype,L", [(torch.float32, 784), (torch.bfloat16, 784), (torch.bfloat16, 196), (torch.bfloat16, 49)])
 def test_x_proj_function(dtype, L):
     """x_proj forward, dX and dW (MFMA kernels in bf16 where the layout allows, library otherwise) against fp64 autograd of

@@ -11,7 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mamba_unet_amd import _lib  # noqa: E402
-from oracle.ss2d_ref import make_scan_inputs  # noqa: E402
+from mamba_unet_amd.synthetic import make_scan_inputs  # noqa: E402
 
 B, K, D, L, N = 24, 4, 192, 3136, 16
 KD = K * D
