@@ -79,7 +79,7 @@ def test_ddp_wrapped_mambaunet_supervised_steps_equal_unwrapped(world_of_one, bf
         den = float(p.grad.norm())
         worst = max(worst, float((p.grad - q.grad).norm()) / (den if den > 0 else 1.0))
     assert worst < (5e-2 if bf16 else 1e-4), worst
-    wmax = max(float((p - q).abs().max()) for p, q in zip(bare.parameters(), twin.parameters()))
+    wmax = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(bare.parameters(), twin.parameters()))
     assert wmax < (1e-3 if bf16 else 1e-6), wmax
 
 
