@@ -1,7 +1,8 @@
 """ss2d_selective_scan_dir_bwd_static -- the entry point that allocates nothing (its dB/dC partial-tile workspace is a
 fixed array inside the library's code object) -- against ss2d_selective_scan_dir_bwd_ws with a caller-allocated
-workspace, through the C ABI: same kernels, so du / ddelta / dB / dC must agree bit for bit and the atomically
-accumulated dA / dD / ddelta_bias to the fp32 gate.  Two calls in a row, the second on a smaller input (the shared
+workspace, through the C ABI: same kernels, so du / ddelta and the plainly stored part of dB / dC must agree bit for
+bit, and what is accumulated with float atomics (dA / dD / ddelta_bias; dB / dC in the chunks that the chunk-pipelined
+kernel splits over its waves: the nchunks % 8 rightmost scan positions' chunks) to the fp32 gate.  Two calls in a row, the second on a smaller input (the shared
 array still holds the first call's partial tiles), then the size / shape rejections."""
 import ctypes
 
@@ -54,8 +55,14 @@ def _case(batch, dim, L, G, rev_mask, u_groups, seed):
     _lib.check(rc, "bwd_ws")
     rc, got = _run(lib, P, "static", inp, ckpt, dout, batch, dim, L, N, G, rev_mask, u_groups, None)
     _lib.check(rc, "bwd_static")
-    for k in ("du", "ddelta", "dB", "dC"):        # plain stores of the same arithmetic: bit for bit
+    for k in ("du", "ddelta"):                    # plain stores of the same arithmetic: bit for bit
         assert torch.equal(got[k], want[k]), k
+    # dB / dC: plain stores too, except in the split chunks of the chunk-pipelined kernel (sequences of >= 8 chunks; 128
+    # positions at the scan's right end = either end of the row in memory, depending on the group's direction)
+    a, b = (128, L - 128) if L >= 8 * 128 else (0, L)
+    for k in ("dB", "dC"):
+        assert torch.equal(got[k][..., a:b], want[k][..., a:b]), k
+        assert rel_l2(got[k].cpu(), want[k].cpu()) < 1e-6 and torch.isfinite(got[k]).all(), k
     for k in ("dA", "dD", "dbias"):               # float atomics: order-dependent in the last bits
         assert rel_l2(got[k].cpu(), want[k].cpu()) < 1e-5, k
         assert torch.isfinite(got[k]).all()
@@ -84,3 +91,48 @@ def test_static_entry_rejects_what_it_cannot_hold():
     zp[6] = P(t)
     rc = lib.ss2d_selective_scan_dir_bwd_static(0, *zp, 1, 8, 32, 16, 4, 1, 4, 0, 0, st)       # z gate
     assert rc == -7 and b"z gate" in lib.ss2d_last_error()
+
+
+def test_static_entry_under_hip_graph_capture_allocates_nothing():
+    """What the entry point exists for: it can be captured in a HIP graph (no allocation, no synchronisation inside) and
+    the device's free memory does not move across calls.  One eager call primes the per-device symbol lookup."""
+    from mamba_unet_amd import _lib
+    from mamba_unet_amd.synthetic import make_scan_inputs
+    lib, P = _lib.load(), _lib.ptr
+    batch, dim, L, N, G = 1, 96, 1792, 16, 4             # 14 chunks: the pipelined kernel with 6 split chunks is not chosen, 8 + would be
+    inp = {k: v.cuda() for k, v in make_scan_inputs(batch, dim, L, dstate=N, ngroups=G, seed=8, integer_A=False).items()}
+    dout = torch.randn(batch, dim, L, generator=torch.Generator().manual_seed(9)).cuda()
+    ckpt = torch.empty(batch, dim, lib.ss2d_scan_num_chunks(L), N, device="cuda")
+    out = torch.empty_like(inp["delta"])
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(lib.ss2d_selective_scan_dir_fwd(0, P(inp["u"]), P(inp["delta"]), P(inp["A"]), P(inp["B"]), P(inp["C"]), P(inp["D"]),
+                                               None, P(inp["delta_bias"]), P(out), None, P(ckpt), batch, dim, L, N, G, 1, G, 0, 0, st), "fwd")
+    ws = torch.empty(int(lib.ss2d_scan_bwd_workspace_bytes(batch, dim, L, N, G)) // 4, device="cuda")
+    rc, want = _run(lib, P, "ws", inp, ckpt, dout, batch, dim, L, N, G, 0, G, ws)
+    _lib.check(rc, "bwd_ws")
+    rc, _ = _run(lib, P, "static", inp, ckpt, dout, batch, dim, L, N, G, 0, G, None)      # primes hipGetSymbolAddress
+    _lib.check(rc, "bwd_static eager")
+    # static output buffers for the captured call
+    dev = dout.device
+    du, ddelta = torch.empty_like(inp["delta"]), torch.empty_like(inp["delta"])
+    acc = torch.zeros(dim * N + 2 * dim, device=dev)
+    dA, dD, dbias = acc[:dim * N].view(dim, N), acc[dim * N:dim * N + dim], acc[dim * N + dim:]
+    dB, dC = torch.empty(batch, G, N, L, device=dev), torch.empty(batch, G, N, L, device=dev)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        acc.zero_()
+        gst = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        rc = lib.ss2d_selective_scan_dir_bwd_static(0, P(inp["u"]), P(inp["delta"]), P(inp["A"]), P(inp["B"]), P(inp["C"]), P(inp["D"]), None,
+                                                    P(inp["delta_bias"]), P(dout), P(ckpt), P(du), P(ddelta), P(dA), P(dB), P(dC), P(dD), None,
+                                                    P(dbias), batch, dim, L, N, G, 1, G, 0, 0, gst)
+    _lib.check(rc, "bwd_static under capture")
+    for _ in range(2):
+        du.fill_(float("nan")); dB.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(du, want["du"]) and torch.equal(ddelta, want["ddelta"])
+        assert torch.equal(dB, want["dB"]) and torch.equal(dC, want["dC"])
+        assert rel_l2(dA.cpu(), want["dA"].cpu()) < 1e-5 and rel_l2(dbias.cpu(), want["dbias"].cpu()) < 1e-5
+    assert torch.cuda.mem_get_info()[0] >= free0          # nothing was allocated by the captured call or its replays
