@@ -16,7 +16,6 @@ struct ScanBwdParams {
     float *ws;           // state-row kernel: partial dB/dC tiles (one per workgroup and (batch, group) it touches), or null = atomics
     const float *dtw;    // fused-delta form (null otherwise): dt_proj weight (dim, R); `delta` then points at the dts rows (R, L) of
     int R;               // every (batch, group) block (block stride bc_stride) and delta = dtw . dts is recomputed in the kernel
-    int split;           // chunk-pipelined kernel: the first `split` = nchunks % 8 chunks run with their channels split over the waves
 };
 
 // The state-row backward (ss2d_scan_bwd_sr.hip): dstate == 16, no z.  Returns a hipError_t / 0.
@@ -24,11 +23,6 @@ struct ScanBwdParams {
 // kernel (deterministic, no zero-fill needed), without it they are accumulated with float atomics.
 int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, float *ws, size_t ws_bytes, hipStream_t s);
 size_t ss2d_scan_bwd_sr_ws_bytes(int batch, int dim, int L, int ngroups);
-// The chunk-pipelined form of the same kernel (ss2d_scan_bwd_srp.hip), chosen by ss2d_scan_bwd_sr_launch for sequences
-// of many chunks; same workspace, same reduction kernel.  `p` arrives with rows_per_wg and ws decided.
-#define SS2D_SRP_ROWS_MAX 72
-bool ss2d_scan_bwd_srp_wanted(int nchunks, int rows_per_wg, int dpg);
-int ss2d_scan_bwd_srp_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, int nwg, hipStream_t s);
 // Device address (on the current device) of the SS2D_STATIC_WS_BYTES workspace that lives in the code object.
 int ss2d_scan_bwd_sr_static_ws(float **ptr);
 

@@ -463,7 +463,7 @@ static int scan_bwd_impl(int dtype, const void *u, const void *delta, const floa
     if (bc_bg_stride < bc_dense) { ss2d_set_error("selective_scan_bwd: bc_bg_stride %lld < dstate*L", bc_bg_stride); return -5; }
     ScanBwdParams p;
     p.Gu = u_groups; p.rev_mask = rev_mask; p.bc_stride = bc_bg_stride;
-    p.dtw = dt_w; p.R = dt_rank; p.ws = nullptr; p.rows_per_wg = 0; p.split = 0;
+    p.dtw = dt_w; p.R = dt_rank; p.ws = nullptr; p.rows_per_wg = 0;
     p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
     p.D = D; p.z = z; p.bias = delta_bias; p.dout = dout; p.ckpt = ckpt;
     p.du = du; p.ddelta = ddelta; p.dA = dA; p.dB = dB; p.dC = dC; p.dD = D ? dD : nullptr;

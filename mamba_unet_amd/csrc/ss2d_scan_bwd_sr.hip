@@ -552,9 +552,6 @@ int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, fl
     p.ws = (ws && (p.L % 4 == 0) && (((uintptr_t)ws | (uintptr_t)p.dB | (uintptr_t)p.dC) & 15) == 0 &&
             ws_bytes >= ss2d_scan_bwd_sr_ws_bytes(p.batch, p.dim, p.L, p.G)) ? ws : nullptr;
     int rc;
-    if (ss2d_scan_bwd_srp_wanted(p.nchunks, p.rows_per_wg, p.dpg) && (!p.dtw || (p.ws && vec4 && (p.R == 6 || p.R == 12)))) {
-        rc = ss2d_scan_bwd_srp_launch(dtype, p, vec4, dirs, (int)nwg, s);   // many chunks: chunk-pipelined waves (ss2d_scan_bwd_srp.hip)
-    } else
     if (p.dtw) {   // fused delta: only the form SS2D issues (4-element rows, direction-aware, workspace), ranks 6 and 12
         if (!p.ws || !vec4 || (p.R != 6 && p.R != 12)) return (int)hipErrorInvalidValue;
         const bool h = dtype == SS2D_DTYPE_BF16;

@@ -17,9 +17,7 @@ B, K, D, L, N = 24, 4, 192, 3136, 16
 KD = K * D
 lib, P = _lib.load(), _lib.ptr
 raw = ctypes.CDLL(_lib.LIB_PATH)
-PIPE = "--pipe" in sys.argv      # the chunk-pipelined kernel: make variant SRC=ss2d_scan_bwd_srp NAME=probep DEFS=-DSS2D_SRP_PROBE
-setter = raw.ss2d_debug_set_probe_p if PIPE else raw.ss2d_debug_set_probe
-setter.argtypes = [ctypes.c_void_p]
+raw.ss2d_debug_set_probe.argtypes = [ctypes.c_void_p]
 NP = 16
 inp = {k: v.cuda() for k, v in make_scan_inputs(B, KD, L, dstate=N, ngroups=K, seed=0).items()}
 dout = torch.randn(B, KD, L, generator=torch.Generator().manual_seed(1)).cuda()
@@ -34,7 +32,7 @@ du, dd = torch.empty_like(out), torch.empty_like(out)
 dA, dD, db = torch.zeros(KD, N, device="cuda"), torch.zeros(KD, device="cuda"), torch.zeros(KD, device="cuda")
 dB, dC = torch.empty(B, K, N, L, device="cuda"), torch.empty(B, K, N, L, device="cuda")
 probe = torch.zeros(256 * 8 * (NP + 1), dtype=torch.int64, device="cuda")
-assert setter(ctypes.c_void_p(probe.data_ptr())) == 0
+assert raw.ss2d_debug_set_probe(ctypes.c_void_p(probe.data_ptr())) == 0
 for it in range(3):
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ev0.record()
@@ -49,11 +47,6 @@ t = t[t[:, NP] > 0]
 tot = t[:, NP].mean().item()
 names = ["0 loop top (next-input loads issue)", "1 softplus+stage+LDS reads", "2 pair0 fwd states", "3 pair0 adjoint local+scan", "4 pair0 true pass",
          "5 pair1 fwd states", "6 pair1 adjoint local+scan", "7 pair1 true pass", "8 flush: second barrier", "9 tile staging (barriers)", "10 flush: slot reads + sum + global store", "11 row sums + record RMW + carry + tile_load issue", "12 (8b) cross-row reductions", "13 (8c) final math + stores", "14 flush: first barrier (wait for all waves)", "15 flush: slot writes"]
-if PIPE:
-    names = ["0 top: next-input loads issue, progress word", "1 strip reads", "2 pair0 fwd states", "3 pair0 adjoint local+scan", "4 pair0 true pass",
-             "5 pair1 fwd states", "6 pair1 adjoint local+scan", "7 pair1 true pass", "8 stage next channel (softplus, strip writes)",
-             "9 cross-row reductions, final math, stores", "10 row sums, LDS atomics, carry, publish", "11 item prologue: B/C tile", "12 item epilogue: dB/dC tile out",
-             "13 wait for the predecessor's carry", "14 -", "15 -"]
 print("waves %d, mean total %.0f ticks" % (t.shape[0], tot))
 for i, n in enumerate(names):
     print("  %-40s %12.0f  %5.1f %%" % (n, t[:, i].mean().item(), 100 * t[:, i].mean().item() / tot))
