@@ -134,7 +134,7 @@ def stream():
     return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
-_ARENA = {}                 # device -> [zero-filled fp32 chunk, floats handed out, capture epoch]
+_ARENA = {}                 # (device, raw stream) -> [zero-filled fp32 chunk, floats handed out, capture epoch]
 _ARENA_EPOCH = [0, False]   # bumped whenever the stream's capture state changes between two requests
 _ARENA_FLOATS = 1 << 23     # 32 MB per chunk: a training step of MambaUNet zero-fills 19 M gradient floats -- three chunks
 _ARENA_MAX_REQ = 1 << 21    # requests above 8 MB get a buffer (and a fill) of their own
@@ -146,7 +146,9 @@ def zeros_flat(device, n):
     gradient buffers of a training step (dgamma, dbeta, dA, dD, bias and small weight gradients: float-atomic targets)
     cost a handful of fill launches instead of one each.  A chunk is never reused -- its pieces must be zero -- and
     lives as long as any piece does; pieces start on 256-byte boundaries.  A chunk filled outside a HIP-graph capture is
-    not used inside one (its fill would not be replayed) and vice versa."""
+    not used inside one (its fill would not be replayed) and vice versa.  Chunks are kept per (device, stream): the fill
+    runs on the stream that is current when the chunk is made, so a piece handed to work on ANOTHER stream would have no
+    ordering against that fill (and the caching allocator could recycle the chunk under it)."""
     import threading
     import torch
     global _ARENA_LOCK
@@ -155,7 +157,8 @@ def zeros_flat(device, n):
     if _ARENA_LOCK is None:
         _ARENA_LOCK = threading.Lock()
     need = (n + 63) // 64 * 64
-    key = str(device)
+    idx = device.index if getattr(device, "index", None) is not None else torch.cuda.current_device()
+    key = (idx, torch._C._cuda_getCurrentRawStream(idx))
     with _ARENA_LOCK:          # forward and autograd threads both come here
         cap = torch.cuda.is_current_stream_capturing()
         if cap != _ARENA_EPOCH[1]:

@@ -495,6 +495,17 @@ static int scan_bwd_impl(int dtype, const void *u, const void *delta, const floa
                          (uintptr_t)ddelta | (uintptr_t)z | (uintptr_t)dz) & amask) == 0);
     hipStream_t s = (hipStream_t)stream;
     const bool dirs = rev_mask != 0 || u_groups != ngroups || bc_bg_stride != bc_dense;
+    // A caller that passes the workspace ss2d_scan_bwd_workspace_bytes() asks for relies on the library WRITING dB / dC
+    // (partial tiles + reduction; it then skips their zero-fill).  Where that path cannot be taken although the shape
+    // qualifies -- a misaligned A, ckpt, dB, dC or workspace -- the call fails instead of accumulating into whatever
+    // dB / dC hold.
+    if (workspace && workspace_bytes > 0 && workspace_bytes >= ss2d_scan_bwd_workspace_bytes(batch, dim, L, dstate, ngroups) &&
+        ss2d_scan_bwd_workspace_bytes(batch, dim, L, dstate, ngroups) > 0 && z == nullptr &&
+        ((((uintptr_t)A | (uintptr_t)ckpt | (uintptr_t)dB | (uintptr_t)dC | (uintptr_t)workspace) & 15) != 0)) {
+        ss2d_set_error("selective_scan_bwd: with a workspace, A, ckpt, dB, dC and the workspace must be 16-byte aligned "
+                       "(dB / dC are written, not accumulated, on that path)");
+        return -7;
+    }
     // the SS2D call pattern: 16 states, no gate -> state-row kernel (SS2D_BWD_KERNEL=general keeps the general one: A/B runs)
     if (dstate == 16 && z == nullptr && !force_general_kernel() && ((((uintptr_t)A | (uintptr_t)ckpt) & 15) == 0)) {
         const int rc = ss2d_scan_bwd_sr_launch(dtype, p, vec4, dirs, static_cast<float *>(workspace), workspace_bytes, s);

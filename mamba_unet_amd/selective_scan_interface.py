@@ -41,7 +41,10 @@ def _prep(t, name, dtype=torch.float32):
         raise RuntimeError(f"selective_scan_fn: `{name}` must be a GPU tensor (no CPU path in mamba_unet_amd)")
     if t.dtype != dtype:
         t = t.to(dtype)
-    return t.contiguous()
+    t = t.contiguous()
+    # the kernels' vector paths (and the workspace form of the backward, which writes dB / dC instead of accumulating them)
+    # want 16-byte aligned bases: a view at an odd storage offset is copied rather than sent down a slower path
+    return t.clone() if t.data_ptr() % 16 else t
 
 
 class SelectiveScanFn(torch.autograd.Function):

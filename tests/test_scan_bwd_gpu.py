@@ -110,3 +110,44 @@ def test_scan_bwd_full_size_adjoint_identity():
     lhs = (dout.double() * yv.double()).sum().item()
     rhs = (u.grad.double() * v.double()).sum().item()
     assert abs(lhs - rhs) / abs(lhs) < 1e-5
+
+
+def test_misaligned_parameter_views_are_handled():
+    """A / D / delta_bias handed over as views at odd storage offsets: selective_scan_fn copies them to aligned
+    storage, and the C ABI refuses the workspace form -- which WRITES dB / dC -- loudly instead of silently accumulating
+    into uninitialised gradients."""
+    import ctypes
+    from mamba_unet_amd import _lib, selective_scan_fn
+    from mamba_unet_amd.synthetic import make_scan_inputs
+    from oracle.selective_scan_ref import selective_scan_ref
+    batch, dim, L, N, G = 2, 32, 256, 16, 4
+    inp = make_scan_inputs(batch, dim, L, dstate=N, ngroups=G, seed=21, integer_A=False)
+    dout = torch.randn(batch, dim, L, generator=torch.Generator().manual_seed(22))
+    ref = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+    selective_scan_ref(ref["u"], ref["delta"], ref["A"], ref["B"], ref["C"], ref["D"], None, ref["delta_bias"], True).backward(dout)
+    gpu = {k: v.cuda() for k, v in inp.items()}
+    pad = torch.zeros(dim * N + 1, device="cuda")
+    pad[1:] = gpu["A"].reshape(-1)
+    A_odd = pad[1:].view(dim, N)                       # 4 bytes past a 16-byte boundary
+    assert A_odd.data_ptr() % 16 == 4
+    leaves = {k: (A_odd if k == "A" else v).detach().requires_grad_(True) for k, v in gpu.items()}
+    y = selective_scan_fn(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"], None, leaves["delta_bias"], True)
+    y.backward(dout.cuda())
+    for k in inp:
+        assert rel_l2(leaves[k].grad.cpu(), ref[k].grad) < 1e-5, k
+    # the C ABI with the same misaligned A and a sufficient workspace: an error, not garbage
+    lib, P = _lib.load(), _lib.ptr
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ckpt = torch.empty(batch, dim, lib.ss2d_scan_num_chunks(L), N, device="cuda")
+    out = torch.empty_like(gpu["u"])
+    _lib.check(lib.ss2d_selective_scan_fwd(0, P(gpu["u"]), P(gpu["delta"]), P(A_odd), P(gpu["B"]), P(gpu["C"]), P(gpu["D"]), None,
+                                           P(gpu["delta_bias"]), P(out), None, P(ckpt), batch, dim, L, N, G, 1, st), "fwd")
+    nb = int(lib.ss2d_scan_bwd_workspace_bytes(batch, dim, L, N, G))
+    assert nb > 0
+    ws = torch.empty(nb // 4, device="cuda")
+    z = lambda *sh: torch.zeros(*sh, device="cuda")           # noqa: E731
+    rc = lib.ss2d_selective_scan_dir_bwd_ws(0, P(gpu["u"]), P(gpu["delta"]), P(A_odd), P(gpu["B"]), P(gpu["C"]), P(gpu["D"]), None,
+                                            P(gpu["delta_bias"]), P(dout.cuda()), P(ckpt), P(torch.empty_like(out)), P(torch.empty_like(out)),
+                                            P(z(dim, N)), P(z(batch, G, N, L)), P(z(batch, G, N, L)), P(z(dim)), None, P(z(dim)),
+                                            batch, dim, L, N, G, 1, G, 0, 0, P(ws), nb, st)
+    assert rc == -7 and b"aligned" in lib.ss2d_last_error()
