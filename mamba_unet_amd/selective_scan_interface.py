@@ -363,7 +363,11 @@ class ScanCoreFn(torch.autograd.Function):
             # dt_proj backward on library GEMMs (K = d contraction for d_dts, K = l for the weight)
             with torch.autocast("cuda", enabled=False):
                 dd4 = ddelta.view(batch, 4, Dch, L)
-                d_dts = torch.matmul(w32.to(io).transpose(1, 2).unsqueeze(0), dd4).contiguous()          # (b, 4, R, l)
+                # d_dts (b, 4, R, l) = dt_w^T . ddelta.  bf16: the own channel-major MFMA kernel; the library's batched GEMM first
+                # materialises the weight once per batch entry (a (b, 4, R, d) copy: 5-26 us per call on top of the product)
+                d_dts = chan_gemm(w32.transpose(1, 2), dd4) if io == torch.bfloat16 else None
+                if d_dts is None:
+                    d_dts = torch.matmul(w32.to(io).transpose(1, 2).unsqueeze(0), dd4).contiguous()
                 # (4, d, R).  bf16: own MFMA kernel (25 / 19 / 13 us at stages 0-2 against the library's 61 / 42 / 28: the
                 # library runs B*4 small products and a sum over the batch); fp32: no faster than the library, which stays
                 d_w = chan_wgrad(dd4, xd[:, :, :R]) if io == torch.bfloat16 else None
