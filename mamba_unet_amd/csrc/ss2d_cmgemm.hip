@@ -176,23 +176,157 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
     }
 }
 
+
+// ---- fp32 operands: the same products on the bf16 MFMA, every fp32 value taken as the exact sum of three bf16 values
+// (split3_bf16, ss2d_common.h), six MFMAs per 16-k product.
+//   * X never visits LDS: with 4-byte elements a lane can read its own MFMA operand -- position l32 of the wave's 32, the
+//     k rows 8h .. 8h+7 of a k-step -- as eight 4-byte reads that are 128 contiguous bytes per row across the lanes, and
+//     splits it in registers;
+//   * the W chunk [96 m][32 k] (shared by the four waves) is split on its way to LDS, into three images;
+//   * the result leaves straight from the accumulators: 32 consecutive positions of one row per store instruction.
+struct CgParamsF {
+    const float *W, *X;
+    float *Y;
+    long long swg, sxb, sxg, syb, syg;
+    int B, G, M, K, ldw, L;              // ldw % 4 == 0 and columns K .. ldw-1 hold zeros
+    int mblocks, ntiles;
+};
+constexpr int FKC = 32, FWROW = 2 * FKC + 16;
+
+// MT: 32-row tiles of W per workgroup (1 for the 6 ... 24 rows of d_dts: a 96-row block would be 3/4 padding there)
+template <int MT>
+__global__ __launch_bounds__(256) void cm_gemm_f32_kernel(const CgParamsF p) {
+    constexpr int FBM = 32 * MT, FWIMG = FBM * FWROW, FWSTAGE = 3 * FWIMG;
+    __shared__ __align__(16) unsigned char lds[2 * FWSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, half = lane >> 5;
+    int blk = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = blk % p.ntiles; blk /= p.ntiles;
+    const int mb = blk % p.mblocks; blk /= p.mblocks;
+    const int g = blk % p.G, b = blk / p.G;
+    const int m0 = mb * FBM, L = p.L;
+    const int pos = nt * BN + 32 * wave + l32;              // this lane's position
+    const bool pos_ok = pos < L;
+    const float *__restrict__ Xl = p.X + (size_t)b * p.sxb + (size_t)g * p.sxg + (pos_ok ? pos : 0);
+    const float *__restrict__ Wg = p.W + (size_t)g * p.swg + (size_t)m0 * p.ldw;
+    float *__restrict__ Yg = p.Y + (size_t)b * p.syb + (size_t)g * p.syg + (size_t)m0 * L;
+    const int nchunks = (p.K + FKC - 1) / FKC;
+    unsigned xr[2][8];                                       // [k-step][k row 8h + i]
+    u32x4 wr[MT];                                            // the W chunk: 32 MT rows x 8 pieces of 16 bytes, MT per thread
+    const int wrow = tid >> 3, wcol = (tid & 7) * 4;         // piece j: row wrow + 32 j, k = wcol .. wcol + 3
+    auto load_chunk = [&](int c) {                           // a chunk past K reads as zeros
+        // never a guarded load: the address is clamped to element 0 and the value masked
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = c * FKC + 16 * ks + 8 * half + i;
+                const bool ok = pos_ok && k < p.K;
+                const unsigned v = *reinterpret_cast<const unsigned *>(Xl + (ok ? (size_t)k * L : 0));
+                xr[ks][i] = v & (ok ? ~0u : 0u);
+            }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int row = wrow + 32 * j, k = c * FKC + wcol;
+            const bool ok = m0 + row < p.M && k < p.ldw;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(Wg + (ok ? (size_t)row * p.ldw + k : 0));
+            wr[j] = v & (ok ? ~0u : 0u);
+        }
+    };
+    auto put_chunk = [&](int stage) {
+        unsigned char *ws = lds + stage * FWSTAGE;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const Split4 sp = split3_bf16(wr[j]);
+            unsigned char *d = ws + (wrow + 32 * j) * FWROW + wcol * 2;
+            *reinterpret_cast<u32x2 *>(d) = sp.h1;
+            *reinterpret_cast<u32x2 *>(d + FWIMG) = sp.h2;
+            *reinterpret_cast<u32x2 *>(d + 2 * FWIMG) = sp.h3;
+        }
+    };
+    f16v acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+    const int woff = l32 * FWROW + 16 * half;
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        const int st = c & 1;
+        put_chunk(st);                                        // stage st was last read two chunks ago, behind the previous barrier
+        u32x4 xf[2][3];                                       // [k-step][rank]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const Split4 lo = split3_bf16(u32x4{xr[ks][0], xr[ks][1], xr[ks][2], xr[ks][3]});
+            const Split4 hi = split3_bf16(u32x4{xr[ks][4], xr[ks][5], xr[ks][6], xr[ks][7]});
+            xf[ks][0] = u32x4{lo.h1.x, lo.h1.y, hi.h1.x, hi.h1.y};
+            xf[ks][1] = u32x4{lo.h2.x, lo.h2.y, hi.h2.x, hi.h2.y};
+            xf[ks][2] = u32x4{lo.h3.x, lo.h3.y, hi.h3.x, hi.h3.y};
+        }
+        load_chunk(c + 1);                                    // in flight during the products (past K: zeros, never used)
+        __syncthreads();
+        const unsigned char *ws = lds + st * FWSTAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 x1 = __builtin_bit_cast(bf16x8, xf[ks][0]), x2 = __builtin_bit_cast(bf16x8, xf[ks][1]), x3 = __builtin_bit_cast(bf16x8, xf[ks][2]);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const unsigned char *wp = ws + mt * 32 * FWROW + woff + 32 * ks;
+                const bf16x8 w1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(wp));
+                const bf16x8 w2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(wp + FWIMG));
+                const bf16x8 w3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4 *>(wp + 2 * FWIMG));
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x2, acc[mt], 0, 0, 0);      // the small terms first
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w3, x1, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x3, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2, x1, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x2, acc[mt], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, x1, acc[mt], 0, 0, 0);
+            }
+        }
+    }
+    // accumulator register e of a 32x32 tile: row (= m) 8*(e/4) + 4*(lane/32) + e%4, column (= position) lane%32
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = 32 * mt + 8 * (e >> 2) + 4 * half + (e & 3);
+            if (pos_ok && m0 + m < p.M) Yg[(size_t)m * L + pos] = acc[mt][e];
+        }
+}
+
 }  // namespace
 
 extern "C" int ss2d_chan_gemm(int dtype, const void *W, const void *X, void *Y, int B, int G, int M, int K, int ldw, int L,
                               long long swg, long long sxb, long long sxg, long long syb, long long syg, void *stream) {
-    if (dtype != SS2D_DTYPE_BF16) { ss2d_set_error("chan_gemm: bf16 only (dtype %d)", dtype); return -1; }
+    if (dtype != SS2D_DTYPE_BF16 && dtype != SS2D_DTYPE_F32) { ss2d_set_error("chan_gemm: unknown dtype %d", dtype); return -1; }
+    const bool f32 = dtype == SS2D_DTYPE_F32;
     if (!W || !X || !Y) { ss2d_set_error("chan_gemm: null required pointer"); return -2; }
     if (B <= 0 || G <= 0 || M <= 0 || K <= 0 || L <= 0 || ldw < K) { ss2d_set_error("chan_gemm: bad size"); return -3; }
-    if (L % 4 || ((sxb | sxg | syb | syg) % 4) || (((uintptr_t)X | (uintptr_t)Y) & 7)) {
+    if (L % 4 || ((sxb | sxg | syb | syg) % 4) || (((uintptr_t)X | (uintptr_t)Y) & (f32 ? 15 : 7))) {
         ss2d_set_error("chan_gemm: L, the block strides of X / Y and their base addresses must be multiples of 4 elements"); return -4; }
-    if (ldw % 8 || swg % 8 || ((uintptr_t)W & 15)) { ss2d_set_error("chan_gemm: W rows must be 16-byte aligned (ldw, group stride multiples of 8)"); return -4; }
+    const int wq = f32 ? 4 : 8;
+    if (ldw % wq || swg % wq || ((uintptr_t)W & 15)) { ss2d_set_error("chan_gemm: W rows must be 16-byte aligned (ldw, group stride multiples of %d)", wq); return -4; }
+    const int fmt = M <= 32 ? 1 : M <= 64 ? 2 : 3;                 // fp32: 32-row tiles per workgroup
+    const int bm = f32 ? 32 * fmt : BM;
+    const int mblocks = (M + bm - 1) / bm, ntiles = (L + BN - 1) / BN;
+    const long long nwg = (long long)B * G * mblocks * ntiles;
+    if (nwg > 0x7fffffffLL) { ss2d_set_error("chan_gemm: grid too large"); return -6; }
+    if (f32) {
+        CgParamsF p;
+        p.W = static_cast<const float *>(W); p.X = static_cast<const float *>(X); p.Y = static_cast<float *>(Y);
+        p.swg = swg; p.sxb = sxb; p.sxg = sxg; p.syb = syb; p.syg = syg;
+        p.B = B; p.G = G; p.M = M; p.K = K; p.ldw = ldw; p.L = L; p.mblocks = mblocks; p.ntiles = ntiles;
+        if (fmt == 1) ss2d_launch(cm_gemm_f32_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+        else if (fmt == 2) ss2d_launch(cm_gemm_f32_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+        else ss2d_launch(cm_gemm_f32_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+        const int rc = ss2d_take_launch_rc();
+        if (rc) ss2d_set_error("chan_gemm: launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return rc;
+    }
     CgParams p;
     p.W = static_cast<const bf16 *>(W); p.X = static_cast<const bf16 *>(X); p.Y = static_cast<bf16 *>(Y);
     p.swg = swg; p.sxb = sxb; p.sxg = sxg; p.syb = syb; p.syg = syg;
     p.B = B; p.G = G; p.M = M; p.K = K; p.ldw = ldw; p.L = L;
-    p.mblocks = (M + BM - 1) / BM; p.ntiles = (L + BN - 1) / BN;
-    const long long nwg = (long long)B * G * p.mblocks * p.ntiles;
-    if (nwg > 0x7fffffffLL) { ss2d_set_error("chan_gemm: grid too large"); return -6; }
+    p.mblocks = mblocks; p.ntiles = ntiles;
     const bool v16 = L % 8 == 0 && ((sxb | sxg | syb | syg) % 8) == 0 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0;
     const bool k64 = K > 128;
     const void *k = v16 ? (k64 ? (const void *)cm_gemm_kernel<true, 64> : (const void *)cm_gemm_kernel<true, 32>)

@@ -13,8 +13,8 @@
 // of every row (256 positions in bf16, 128 in fp32) of one batch entry, brought into LDS with coalesced 16-byte reads
 // (a first version read its MFMA operands straight from memory, one row per lane: 64 cache lines per load instruction,
 // 3 us per step).  Each wave multiplies a quarter of the step's positions out of LDS (one ds_read_b128 per operand and
-// MFMA K-step, rows 528 bytes apart: conflict-free), bf16: v_mfma_f32_32x32x16_bf16 (exact products, fp32 sums); fp32:
-// v_mfma_f32_32x32x2_f32.  At the end the four waves add their tiles in LDS by turns and the workgroup sends one set of
+// MFMA K-step, rows 528 bytes apart: conflict-free) on v_mfma_f32_32x32x16_bf16 (exact products, fp32 sums); fp32 operands
+// enter it as three-way bf16 splits, six products each (mfma_step).  At the end the four waves add their tiles in LDS by turns and the workgroup sends one set of
 // fp32 atomics (out is ACCUMULATED INTO: the caller zero-fills).
 #include "ss2d_common.h"
 #include "../../include/ss2d.h"
@@ -45,16 +45,27 @@ __device__ __forceinline__ void mfma_step(const u4 (&a)[4], const u4 (&b)[NT][4]
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q]), __builtin_bit_cast(bf16x8, b[j][q]), acc[j], 0, 0, 0);
     } else {
+        // fp32 on the bf16 MFMA: the lane's 16 consecutive positions are two k-steps of 8; every value enters as the exact
+        // sum of three bf16 values, six products kept (split3_bf16, ss2d_common.h) -- 12 MFMAs at the bf16 rate in place of
+        // 16 v_mfma_f32_32x32x2_f32 at 1/16 of it
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f4 af = __builtin_bit_cast(f4, a[q]);     // (components named one by one: indexing by the unrolled loop variable
-#pragma unroll                                              //  made the compiler use component 0 four times)
+        for (int ks = 0; ks < 2; ++ks) {
+            const Split4 alo = split3_bf16(a[2 * ks]), ahi = split3_bf16(a[2 * ks + 1]);
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, u4{alo.h1.x, alo.h1.y, ahi.h1.x, ahi.h1.y});
+            const bf16x8 a2 = __builtin_bit_cast(bf16x8, u4{alo.h2.x, alo.h2.y, ahi.h2.x, ahi.h2.y});
+            const bf16x8 a3 = __builtin_bit_cast(bf16x8, u4{alo.h3.x, alo.h3.y, ahi.h3.x, ahi.h3.y});
+#pragma unroll
             for (int j = 0; j < NT; ++j) {
-                const f4 bf = __builtin_bit_cast(f4, b[j][q]);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf.x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf.y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf.z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf.w, acc[j], 0, 0, 0);
+                const Split4 blo = split3_bf16(b[j][2 * ks]), bhi = split3_bf16(b[j][2 * ks + 1]);
+                const bf16x8 b1 = __builtin_bit_cast(bf16x8, u4{blo.h1.x, blo.h1.y, bhi.h1.x, bhi.h1.y});
+                const bf16x8 b2 = __builtin_bit_cast(bf16x8, u4{blo.h2.x, blo.h2.y, bhi.h2.x, bhi.h2.y});
+                const bf16x8 b3 = __builtin_bit_cast(bf16x8, u4{blo.h3.x, blo.h3.y, bhi.h3.x, bhi.h3.y});
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[j], 0, 0, 0);      // the small terms first
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[j], 0, 0, 0);
             }
         }
     }

@@ -336,3 +336,31 @@ __device__ __forceinline__ f4 buf_load4m(__amdgpu_buffer_rsrc_t rs, unsigned row
     }
     return r;
 }
+
+// ---- fp32 operands on the bf16 MFMA.  An fp32 value is the EXACT sum of three bf16 values -- its top 8 significant bits,
+// the next 8 and the last 8, taken by truncation: v = h1 + h2 + h3 with |h2| < 2^-7 |v|, |h3| < 2^-15 |v|.  A product of two
+// such sums keeps six terms (h1h1, h1h2, h2h1, h1h3, h3h1, h2h2); the three dropped ones are below 2^-21 of the product,
+// the rounding level of a long fp32 accumulation.  Six v_mfma_f32_32x32x16_bf16 (exact bf16 products, fp32 sums) then do the
+// work of eight v_mfma_f32_32x32x2_f32 in 3/8 of the MFMA cycles: the fp32 GEMMs of this library are built on this.
+// (Inf / NaN: inf - inf in the remainder turns an Inf operand into NaN products.)
+struct Split4 { u32x2 h1, h2, h3; };          // four fp32 values -> four bf16 values of each rank
+__device__ __forceinline__ unsigned bf16_hi_pair(unsigned lo, unsigned hi) {   // the upper halves of two registers in one
+    return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
+}
+__device__ __forceinline__ Split4 split3_bf16(const u32x4 v) {
+    const unsigned u0 = v.x, u1 = v.y, u2 = v.z, u3 = v.w;       // (components by name: see buf_store2m)
+    const float r0 = __builtin_bit_cast(float, u0) - __builtin_bit_cast(float, u0 & 0xffff0000u);
+    const float r1 = __builtin_bit_cast(float, u1) - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const float r2 = __builtin_bit_cast(float, u2) - __builtin_bit_cast(float, u2 & 0xffff0000u);
+    const float r3 = __builtin_bit_cast(float, u3) - __builtin_bit_cast(float, u3 & 0xffff0000u);
+    const unsigned s0 = __builtin_bit_cast(unsigned, r0), s1 = __builtin_bit_cast(unsigned, r1);
+    const unsigned s2 = __builtin_bit_cast(unsigned, r2), s3 = __builtin_bit_cast(unsigned, r3);
+    const float q0 = r0 - __builtin_bit_cast(float, s0 & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, s1 & 0xffff0000u);
+    const float q2 = r2 - __builtin_bit_cast(float, s2 & 0xffff0000u), q3 = r3 - __builtin_bit_cast(float, s3 & 0xffff0000u);
+    Split4 o;
+    o.h1 = u32x2{bf16_hi_pair(u0, u1), bf16_hi_pair(u2, u3)};
+    o.h2 = u32x2{bf16_hi_pair(s0, s1), bf16_hi_pair(s2, s3)};
+    o.h3 = u32x2{bf16_hi_pair(__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)),
+                 bf16_hi_pair(__builtin_bit_cast(unsigned, q2), __builtin_bit_cast(unsigned, q3))};
+    return o;
+}

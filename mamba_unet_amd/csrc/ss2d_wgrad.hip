@@ -420,6 +420,148 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p)
 #endif
 }
 
+
+// ---- fp32 operands, LDS-staged, on the bf16 MFMA: the kernel above with every fp32 value split on its way to LDS into the
+// exact sum of three bf16 values (split3_bf16, ss2d_common.h: three images of the chunk) and six MFMAs per product --
+// fp32 products and sums at 3/8 of the MFMA cycles of v_mfma_f32_32x32x2_f32 (wgrad_kernel<float>), and operands read as
+// whole 16-byte pieces.  A chunk is 16 tokens (one MFMA k-step); two stages of three images are 48 KB of LDS and the launch
+// aims at three workgroups per CU: with one, the splitting (VALU), the MFMAs and the memory round trips of a workgroup add
+// up instead of overlapping.  Needs M, N, lda, ldb multiples of 4 and 16-byte aligned operands.
+constexpr int FTKC = 16, FTIMG_A = FTKC * TAROW, FTIMG_B = FTKC * TBROW, FTSTAGE = 3 * (FTIMG_A + FTIMG_B);
+
+__global__ __launch_bounds__(256) void wgrad_f32_tr_kernel(const WgradParams p) {
+    __shared__ __align__(16) unsigned char lds[2 * FTSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int lid = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tile = lid % tiles;
+    const int m0 = (tile / p.tiles_n) * TM, n0 = (tile % p.tiles_n) * TN;
+    const long long r0 = (long long)(lid / tiles) * p.slab;
+    long long r1 = r0 + p.slab;
+    r1 = r1 < p.rows ? r1 : p.rows;
+    const float *__restrict__ A = static_cast<const float *>(p.A);
+    const float *__restrict__ B = static_cast<const float *>(p.B);
+    // this thread's pieces of a chunk: 2 of A (16 rows x 32 pieces of 4 floats), 1.5 of B (16 rows x 24 pieces); two chunks in
+    // flight in registers (set = stage = chunk parity)
+    constexpr int NA = FTKC * 32 / 256, NB = (FTKC * 24 + 255) / 256;
+    u32x4 pa[2][NA], pb[2][NB];
+    int brow[NB], bcol[NB];
+    bool bon[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int id = j * 256 + tid;
+        bon[j] = id < FTKC * 24;
+        brow[j] = (bon[j] ? id : 0) / 24; bcol[j] = ((bon[j] ? id : 0) - brow[j] * 24) * 4;
+    }
+    const int arow = tid >> 5, acol = (tid & 31) * 4;          // piece j: row arow + 8 j
+    constexpr std::integral_constant<int, 0> S0{};
+    constexpr std::integral_constant<int, 1> S1{};
+    auto load_chunk = [&](auto set, long long rc) {              // rows at or past r1 (also whole chunks) read as zeros
+        constexpr int S = decltype(set)::value;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const long long row = rc + arow + 8 * j;
+            const bool ok = row < r1 && m0 + acol < p.M;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(A + (ok ? row * p.lda + m0 + acol : 0));
+            pa[S][j] = v & (ok ? ~0u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const long long row = rc + brow[j];
+            const bool ok = bon[j] && row < r1 && n0 + bcol[j] < p.N;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(B + (ok ? row * p.ldb + n0 + bcol[j] : 0));
+            pb[S][j] = v & (ok ? ~0u : 0u);
+        }
+    };
+    auto put_chunk = [&](auto set) {
+        constexpr int S = decltype(set)::value;
+        unsigned char *as = lds + S * FTSTAGE, *bs = as + 3 * FTIMG_A;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const Split4 sp = split3_bf16(pa[S][j]);
+            unsigned char *d = as + (arow + 8 * j) * TAROW + acol * 2;
+            *reinterpret_cast<u32x2 *>(d) = sp.h1;
+            *reinterpret_cast<u32x2 *>(d + FTIMG_A) = sp.h2;
+            *reinterpret_cast<u32x2 *>(d + 2 * FTIMG_A) = sp.h3;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (!bon[j]) continue;
+            const Split4 sp = split3_bf16(pb[S][j]);
+            unsigned char *d = bs + brow[j] * TBROW + bcol[j] * 2;
+            *reinterpret_cast<u32x2 *>(d) = sp.h1;
+            *reinterpret_cast<u32x2 *>(d + FTIMG_B) = sp.h2;
+            *reinterpret_cast<u32x2 *>(d + 2 * FTIMG_B) = sp.h3;
+        }
+    };
+    f16v acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.0f;
+    const int gq = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;          // transposed read: see wgrad_bf16_tr_kernel
+    const int trow = 8 * (gq >> 1) + q, tcol = (16 * (gq & 1) + 4 * pp) * 2;
+    const int aoff = trow * TAROW + 64 * wave + tcol, boff = trow * TBROW + tcol;
+    const bool live = m0 + 32 * wave < p.M;
+    const long long nchunks = r1 > r0 ? (r1 - r0 + FTKC - 1) / FTKC : 0;
+    auto products = [&](auto set) {
+        constexpr int s = decltype(set)::value;
+        if (live) {
+            typedef s16x4 __attribute__((address_space(3))) *lp;
+            const unsigned char *as = lds + s * FTSTAGE + aoff, *bs = lds + s * FTSTAGE + 3 * FTIMG_A + boff;
+#pragma unroll
+            for (int ks = 0; ks < FTKC / 16; ++ks) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(as + i * FTIMG_A + 16 * ks * TAROW));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(as + i * FTIMG_A + (16 * ks + 4) * TAROW));
+                    af[i] = __builtin_bit_cast(bf16x8, s16x8{a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w});
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    bf16x8 bf[3];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bs + i * FTIMG_B + 16 * ks * TBROW + 64 * j));
+                        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lp)(bs + i * FTIMG_B + (16 * ks + 4) * TBROW + 64 * j));
+                        bf[i] = __builtin_bit_cast(bf16x8, s16x8{b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w});
+                    }
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc[j], 0, 0, 0);      // the small terms first
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    if (nchunks > 0) { load_chunk(S0, r0); load_chunk(S1, r0 + FTKC); }
+    for (long long c = 0; c < nchunks; c += 2) {                 // see wgrad_bf16_tr_kernel
+        put_chunk(S0);
+        load_chunk(S0, r0 + (c + 2) * FTKC);
+        __syncthreads();
+        products(S0);
+        put_chunk(S1);
+        load_chunk(S1, r0 + (c + 3) * FTKC);
+        __syncthreads();
+        products(S1);
+    }
+    if (live && nchunks > 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int n = n0 + 32 * j + l32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + 32 * wave + 8 * (e >> 2) + 4 * half + (e & 3);
+                if (m < p.M && n < p.N) atomicAdd(p.C + (size_t)m * p.ldc + n, acc[j][e]);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float *C, long long rows, int M, int N,
@@ -432,11 +574,14 @@ extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float 
     p.A = A; p.B = B; p.C = C; p.rows = rows; p.M = M; p.N = N; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     static const bool env_direct = getenv("SS2D_WGRAD_DIRECT") != nullptr;   // A/B against the direct-read bf16 form, read once
     static const bool env_widen = getenv("SS2D_WGRAD_WIDEN") != nullptr;     // A/B against the fp32-MFMA form, read once
-    const bool use_tr = dtype == SS2D_DTYPE_BF16 && !env_widen && !env_direct && M % 8 == 0 && N % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 &&
+    const int q16 = dtype == SS2D_DTYPE_BF16 ? 8 : 4;            // elements per 16 bytes
+    // (fp32 with SS2D_WGRAD_WIDEN: the fp32-MFMA form, for A/B)
+    const bool use_tr = !env_widen && !(env_direct && dtype == SS2D_DTYPE_BF16) && M % q16 == 0 && N % q16 == 0 && lda % q16 == 0 && ldb % q16 == 0 &&
                         ((((uintptr_t)A | (uintptr_t)B) & 15) == 0);
     long long target_waves = 1024;
     static const long long env_waves = ss2d_env_ll("SS2D_WGRAD_WAVES", 0);   // tuning knob, read once
     if (env_waves >= 4 && env_waves <= 65536) target_waves = env_waves;
+    else if (use_tr && dtype == SS2D_DTYPE_F32) target_waves = 3072;                 // three workgroups per CU (wgrad_f32_tr_kernel: 1024 / 2048 / 3072 -> 74 / 69 / 64 us at stage 0)
     else if (use_tr && (double)rows * (M + N) * 2.0 > 150e6) target_waves = 1536;   // 246 MB final expand: 60 us against 78
     long long nwg;
     if (use_tr) {
@@ -469,7 +614,8 @@ extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float 
     }
     if (nwg > 0x7fffffffLL) { ss2d_set_error("linear_wgrad: grid too large"); return -6; }
     hipStream_t s = (hipStream_t)stream;
-    if (use_tr) ss2d_launch(wgrad_bf16_tr_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    if (use_tr && dtype == SS2D_DTYPE_F32) ss2d_launch(wgrad_f32_tr_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);
+    else if (use_tr) ss2d_launch(wgrad_bf16_tr_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);
     else if (dtype == SS2D_DTYPE_BF16 && !env_widen) ss2d_launch(wgrad_bf16_kernel, dim3((unsigned)nwg), dim3(256), 0, s, p);   // env: A/B against the fp32-MFMA form
     else if (dtype == SS2D_DTYPE_BF16) ss2d_launch(wgrad_kernel<bf16>, dim3((unsigned)nwg), dim3(256), 0, s, p);
     else ss2d_launch(wgrad_kernel<float>, dim3((unsigned)nwg), dim3(256), 0, s, p);

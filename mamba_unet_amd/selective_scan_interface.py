@@ -287,7 +287,7 @@ class ScanCoreFn(torch.autograd.Function):
                 rc = lib.ss2d_dt_proj_fwd(code, _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(delta), batch, 4, Dch, R, L, Cx * L, _stream())
                 _lib.check(rc, "ss2d_dt_proj_fwd")
             else:   # other ranks (24 / 48 at stages 2 / 3): bf16 MFMA kernel over the dts rows in place, else the library GEMM
-                delta = chan_gemm(w32, xd[:, :, :R]) if io == torch.bfloat16 else None
+                delta = chan_gemm(w32, xd[:, :, :R])
                 if delta is None:
                     with torch.autocast("cuda", enabled=False):
                         delta = torch.matmul(w32.to(io).unsqueeze(0), xd[:, :, :R])
@@ -365,12 +365,13 @@ class ScanCoreFn(torch.autograd.Function):
                 dd4 = ddelta.view(batch, 4, Dch, L)
                 # d_dts (b, 4, R, l) = dt_w^T . ddelta.  bf16: the own channel-major MFMA kernel; the library's batched GEMM first
                 # materialises the weight once per batch entry (a (b, 4, R, d) copy: 5-26 us per call on top of the product)
-                d_dts = chan_gemm(w32.transpose(1, 2), dd4) if io == torch.bfloat16 else None
+                d_dts = chan_gemm(w32.transpose(1, 2), dd4)
                 if d_dts is None:
                     d_dts = torch.matmul(w32.to(io).transpose(1, 2).unsqueeze(0), dd4).contiguous()
-                # (4, d, R).  bf16: own MFMA kernel (25 / 19 / 13 us at stages 0-2 against the library's 61 / 42 / 28: the
-                # library runs B*4 small products and a sum over the batch); fp32: no faster than the library, which stays
-                d_w = chan_wgrad(dd4, xd[:, :, :R]) if io == torch.bfloat16 else None
+                # (4, d, R): own MFMA kernel (bf16 25 / 19 / 13 us at stages 0-2 against the library's 61 / 42 / 28, fp32 -- as
+                # three-way bf16 splits -- 65 / 37 / 23 against 66 / 66 / 57: the library runs B*4 small products and a sum
+                # over the batch)
+                d_w = chan_wgrad(dd4, xd[:, :, :R])
                 if d_w is None:
                     d_w = torch.matmul(dd4, xd[:, :, :R].transpose(2, 3)).sum(0, dtype=torch.float32)
             rc = lib.ss2d_xdbl_grad_pack(code, _lib.ptr(d_dts), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(d_xdbl), batch * 4, R, N, L, _stream())

@@ -234,23 +234,26 @@ def chan_wgrad(P: torch.Tensor, Q: torch.Tensor) -> torch.Tensor:
 
 
 def chan_gemm(W: torch.Tensor, X: torch.Tensor):
-    """Y (B, G, M, L) bf16 = W (G, M, K) @ X (B, G, K, L) for a channel-major bf16 X whose rows are L apart (row ranges of
-    wider blocks are fine): x_proj, dt_proj and their input gradients (mamba_sys.py:407, :420) on the MFMA kernel of
-    csrc/ss2d_cmgemm.hip.  None when dtype or layout do not qualify (the caller then uses the BLAS library)."""
+    """Y (B, G, M, L) = W (G, M, K) @ X (B, G, K, L) for a channel-major X (bf16 or fp32) whose rows are L apart (row ranges
+    of wider blocks are fine): x_proj, dt_proj and their input gradients (mamba_sys.py:407, :420) on the MFMA kernels of
+    csrc/ss2d_cmgemm.hip (fp32: three-way bf16 split, fp32 results).  Y has X's dtype.  None when dtype or layout do not
+    qualify (the caller then uses the BLAS library)."""
     _need_gpu(X, "chan_gemm")
     B, G, K, L = X.shape
     M = W.shape[1]
-    if X.dtype != torch.bfloat16 or W.shape[0] != G or W.shape[2] != K or L % 4:
+    if X.dtype not in (torch.bfloat16, torch.float32) or W.shape[0] != G or W.shape[2] != K or L % 4:
         return None
-    if not (X.stride(3) == 1 and X.stride(2) == L and X.stride(0) % 4 == 0 and X.stride(1) % 4 == 0) or X.data_ptr() % 8:
+    f32 = X.dtype == torch.float32
+    if not (X.stride(3) == 1 and X.stride(2) == L and X.stride(0) % 4 == 0 and X.stride(1) % 4 == 0) or X.data_ptr() % (16 if f32 else 8):
         return None
-    ldw = (K + 7) // 8 * 8
-    Wp = W.to(torch.bfloat16)
+    q = 4 if f32 else 8                                               # W rows are padded with zeros to 16 bytes
+    ldw = (K + q - 1) // q * q
+    Wp = W.to(X.dtype)
     Wp = torch.nn.functional.pad(Wp, (0, ldw - K)) if ldw != K else Wp.contiguous()
-    Y = torch.empty((B, G, M, L), device=X.device, dtype=torch.bfloat16)
+    Y = torch.empty((B, G, M, L), device=X.device, dtype=X.dtype)
     with _lib.on_device(X.device):
-        rc = _lib.load().ss2d_chan_gemm(_BF16, _lib.ptr(Wp), _lib.ptr(X), _lib.ptr(Y), B, G, M, K, ldw, L, M * ldw, X.stride(0),
-                                        X.stride(1), G * M * L, M * L, _stream())
+        rc = _lib.load().ss2d_chan_gemm(_F32 if f32 else _BF16, _lib.ptr(Wp), _lib.ptr(X), _lib.ptr(Y), B, G, M, K, ldw, L, M * ldw,
+                                        X.stride(0), X.stride(1), G * M * L, M * L, _stream())
     _lib.check(rc, "ss2d_chan_gemm")
     return Y
 
@@ -268,7 +271,7 @@ class _XProj(torch.autograd.Function):
         w2 = w.to(xs.dtype)
         ctx.save_for_backward(w2, xs)
         ctx.w_dtype = w.dtype
-        y = chan_gemm(w2, xs) if xs.dtype == torch.bfloat16 else None
+        y = chan_gemm(w2, xs)
         if y is None:
             with torch.autocast("cuda", enabled=False):
                 y = torch.matmul(w2.unsqueeze(0), xs)
@@ -282,7 +285,7 @@ class _XProj(torch.autograd.Function):
         dxs = dw = None
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[1]:
-                dxs = chan_gemm(w2.transpose(1, 2), g) if g.dtype == torch.bfloat16 else None
+                dxs = chan_gemm(w2.transpose(1, 2), g)
                 if dxs is None:
                     dxs = torch.matmul(w2.transpose(1, 2).unsqueeze(0), g)
             if ctx.needs_input_grad[0]:
@@ -320,24 +323,26 @@ _OWN_TOKEN_GEMM = not os.environ.get("SS2D_LIBRARY_LINEAR")      # A/B switch: t
 
 
 def token_gemm(a: torch.Tensor, w: torch.Tensor, k_major: bool):
-    """a (..., K) bf16 times a weight: k_major False -> a @ w.T with w (N, K) (F.linear); True -> a @ w with w (K, N) (the
-    input gradient of F.linear) -- csrc/ss2d_tokgemm.hip.  Returns (..., N) bf16, or None when dtype / layout do not
-    qualify (the caller then uses the BLAS library)."""
-    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not a.is_cuda or w.dim() != 2:
+    """a (..., K) times a weight: k_major False -> a @ w.T with w (N, K) (F.linear); True -> a @ w with w (K, N) (the
+    input gradient of F.linear) -- csrc/ss2d_tokgemm.hip.  bf16, or fp32 (three-way bf16 split on the same MFMA: fp32
+    results).  Returns (..., N) in the operands' dtype, or None when dtype / layout do not qualify (the caller then uses the
+    BLAS library)."""
+    if a.dtype not in (torch.bfloat16, torch.float32) or w.dtype != a.dtype or not a.is_cuda or w.dim() != 2:
         return None
+    q = 16 // a.element_size()                                        # elements per 16 bytes
     K = a.shape[-1]
     N = w.shape[1] if k_major else w.shape[0]
-    if (w.shape[0] if k_major else w.shape[1]) != K or K % 8 or N % 8 or w.stride(1) != 1 or w.stride(0) % 8 or w.data_ptr() % 16:
+    if (w.shape[0] if k_major else w.shape[1]) != K or K % q or N % q or w.stride(1) != 1 or w.stride(0) % q or w.data_ptr() % 16:
         return None                                                   # a column range of a wider weight is fine (_ConcatLinear)
     a2 = a.reshape(-1, K)
     if a2.shape[0] == 0 or a2.stride(1) != 1 or a2.data_ptr() % 16:
         return None
     lda = a2.stride(0) if a2.shape[0] > 1 else K
-    if lda % 8 or lda < K:
+    if lda % q or lda < K:
         return None
-    out = torch.empty((a2.shape[0], N), device=a.device, dtype=torch.bfloat16)
+    out = torch.empty((a2.shape[0], N), device=a.device, dtype=a.dtype)
     with _lib.on_device(a.device):
-        rc = _lib.load().ss2d_token_gemm(_BF16, _lib.ptr(a2), _lib.ptr(w), _lib.ptr(out), a2.shape[0], N, K, lda,
+        rc = _lib.load().ss2d_token_gemm(_io(a)[1], _lib.ptr(a2), _lib.ptr(w), _lib.ptr(out), a2.shape[0], N, K, lda,
                                          w.stride(0), N, int(k_major), _stream())
     _lib.check(rc, "ss2d_token_gemm")
     return out.view(*a.shape[:-1], N)
@@ -345,9 +350,11 @@ def token_gemm(a: torch.Tensor, w: torch.Tensor, k_major: bool):
 
 def _own_wgrad_pays(rows: int, m: int, n: int, dtype) -> bool:
     """Split-token MFMA weight gradient or the library's g^T x: the own kernel wins wherever the token axis is long against
-    the output (stages 0 / 1, fp32 and bf16) and, in bf16, down to ~2000 tokens (stage 2: 21-28 us against 37; at the 1176
-    tokens of stage 3 they tie) -- tools/wgrad_shapes_bench.py."""
-    return rows >= 32 * min(m, n) or (dtype == torch.bfloat16 and rows >= 2048 and m % 8 == 0 and n % 8 == 0)
+    the output (stages 0 / 1) and, with 16-byte aligned rows (the LDS-staged kernels, bf16 and fp32), down to ~2000 tokens
+    (stage 2: bf16 21-28 us against 37, fp32 37-58 against 43-66; at the 1176 tokens of stage 3 they tie or the library
+    wins) -- tools/wgrad_shapes_bench.py."""
+    q = 8 if dtype == torch.bfloat16 else 4
+    return rows >= 32 * min(m, n) or (rows >= 2048 and m % q == 0 and n % q == 0)
 
 
 def _lib_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
@@ -355,10 +362,14 @@ def _lib_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return g2.t() @ x.reshape(g2.shape[0], -1)
 
 
-def _token_gemm_pays(tokens: int, n: int, k: int) -> bool:
+def _token_gemm_pays(tokens: int, n: int, k: int, dtype=torch.bfloat16) -> bool:
     """The own kernel walks the whole contraction in one workgroup per 128 x 96 tile: with a long contraction and too few
-    tiles to fill 256 CUs (stage 3: 1176 tokens) the library's split is faster (tools/token_gemm_bench.py)."""
-    return _OWN_TOKEN_GEMM and not (k >= 1536 and ((tokens + 127) // 128) * ((n + 95) // 96) < 256)
+    tiles to fill 256 CUs (stage 3: 1176 tokens) the library's split is faster (tools/token_gemm_bench.py).  fp32 (six MFMAs
+    per product): the own kernel wins from one tile per CU on (stages 0-2 except the 148-tile products), the library below."""
+    tiles = ((tokens + 127) // 128) * ((n + 95) // 96)
+    if dtype == torch.float32:
+        return _OWN_TOKEN_GEMM and tiles >= 256
+    return _OWN_TOKEN_GEMM and not (k >= 1536 and tiles < 256)
 
 
 _WORKING_COPIES = {}      # id(parameter) -> (weakref to it, low-precision copy, parameter._version when the copy was made)
@@ -378,17 +389,19 @@ def cast_weight(p: torch.Tensor, dt) -> torch.Tensor:
 
 
 def token_gemm_cat(a: torch.Tensor, a2, w: torch.Tensor, bias):
-    """[a | a2] @ w.T + bias in bf16 (fp32 accumulation, fp32 bias added before rounding) without the concatenation --
-    csrc/ss2d_tokgemm.hip.  a (..., K1), a2 (..., K2) or None, w (N, K1 + K2), bias (N) fp32 or None.  None when dtype /
-    layout do not qualify."""
-    if a.dtype != torch.bfloat16 or w.dtype != torch.bfloat16 or not a.is_cuda or w.dim() != 2:
+    """[a | a2] @ w.T + bias (fp32 accumulation, fp32 bias added before any rounding) without the concatenation --
+    csrc/ss2d_tokgemm.hip.  a (..., K1), a2 (..., K2) or None, w (N, K1 + K2), all bf16 or all fp32; bias (N) fp32 or None.
+    None when dtype / layout do not qualify."""
+    if a.dtype not in (torch.bfloat16, torch.float32) or w.dtype != a.dtype or not a.is_cuda or w.dim() != 2:
         return None
+    f32 = a.dtype == torch.float32
+    q = 4 if f32 else 8                                               # elements per 16 bytes
     K1 = a.shape[-1]
     K2 = 0 if a2 is None else a2.shape[-1]
     N, K = w.shape
-    if K != K1 + K2 or K % 8 or N % 8 or w.stride(1) != 1 or w.stride(0) % 8 or w.data_ptr() % 16:
+    if K != K1 + K2 or K % q or N % q or w.stride(1) != 1 or w.stride(0) % q or w.data_ptr() % 16:
         return None
-    if a2 is not None and (a2.dtype != torch.bfloat16 or a2.shape[:-1] != a.shape[:-1] or K1 % (64 if K > 256 else 32)):
+    if a2 is not None and (a2.dtype != a.dtype or a2.shape[:-1] != a.shape[:-1] or K1 % (32 if f32 else 64 if K > 256 else 32)):
         return None
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.data_ptr() % 16 or bias.numel() != N):
         return None
@@ -399,22 +412,22 @@ def token_gemm_cat(a: torch.Tensor, a2, w: torch.Tensor, bias):
             continue
         t2 = t.reshape(-1, t.shape[-1])
         ld = t2.stride(0) if t2.shape[0] > 1 else t2.shape[1]
-        if t2.shape[0] == 0 or t2.stride(1) != 1 or t2.data_ptr() % 16 or ld % 8 or ld < t2.shape[1]:
+        if t2.shape[0] == 0 or t2.stride(1) != 1 or t2.data_ptr() % 16 or ld % q or ld < t2.shape[1]:
             return None
         ops.append((t2, ld))
     (a_, lda), (a2_, lda2) = ops
-    out = torch.empty((a_.shape[0], N), device=a.device, dtype=torch.bfloat16)
+    out = torch.empty((a_.shape[0], N), device=a.device, dtype=a.dtype)
     with _lib.on_device(a.device):
-        rc = _lib.load().ss2d_token_gemm_cat(_BF16, _lib.ptr(a_), _lib.ptr(a2_), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), a_.shape[0],
+        rc = _lib.load().ss2d_token_gemm_cat(_io(a)[1], _lib.ptr(a_), _lib.ptr(a2_), _lib.ptr(w), _lib.ptr(bias), _lib.ptr(out), a_.shape[0],
                                              N, K, K1, lda, lda2, w.stride(0), N, _stream())
     _lib.check(rc, "ss2d_token_gemm_cat")
     return out.view(*a.shape[:-1], N)
 
 
 class _Linear(torch.autograd.Function):
-    """y = x W^T (+ b) for the Linears whose token axis dwarfs both feature axes: bf16 forward and dX on the token-major
-    MFMA kernel (ss2d_token_gemm; hipBLASLt for fp32, with a bias, and where _token_gemm_pays says no), dW on the
-    split-token MFMA kernel, db a column sum."""
+    """y = x W^T (+ b) for the Linears whose token axis dwarfs both feature axes: forward and dX on the token-major MFMA
+    kernel (ss2d_token_gemm: bf16, or fp32 as a three-way bf16 split; hipBLASLt with a non-fp32 bias and where
+    _token_gemm_pays says no), dW on the split-token MFMA kernel, db a column sum."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -429,7 +442,7 @@ class _Linear(torch.autograd.Function):
         y = None
         # bf16: own MFMA kernel.  Its bias input is fp32 (added before the rounding): a bias of any other dtype (a module
         # converted with .bfloat16(), no autocast) goes to the library below -- never silently without its bias
-        if _token_gemm_pays(x.numel() // x.shape[-1], w.shape[0], w.shape[1]) and (bias is None or bias.dtype == torch.float32):
+        if _token_gemm_pays(x.numel() // x.shape[-1], w.shape[0], w.shape[1], x.dtype) and (bias is None or bias.dtype == torch.float32):
             y = token_gemm(x, w, False) if bias is None else token_gemm_cat(x, None, w, bias)
         if y is not None:
             return y
@@ -442,7 +455,7 @@ class _Linear(torch.autograd.Function):
         g = g.to(x.dtype)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = token_gemm(g, w, True) if _token_gemm_pays(g.numel() // g.shape[-1], w.shape[1], w.shape[0]) else None
+            dx = token_gemm(g, w, True) if _token_gemm_pays(g.numel() // g.shape[-1], w.shape[1], w.shape[0], g.dtype) else None
             if dx is None:
                 dx = torch.matmul(g, w)
         dw = None
@@ -474,7 +487,7 @@ class _ConcatLinear(torch.autograd.Function):
         ctx.save_for_backward(x, skip, w)
         ctx.w_dtype, ctx.b_dtype = weight.dtype, None if bias is None else bias.dtype
         y = None
-        if _token_gemm_pays(x.numel() // C1, w.shape[0], w.shape[1]) and (bias is None or bias.dtype == torch.float32):
+        if _token_gemm_pays(x.numel() // C1, w.shape[0], w.shape[1], x.dtype) and (bias is None or bias.dtype == torch.float32):
             y = token_gemm_cat(x, skip, w, bias)                       # both halves and the bias in one pass
         if y is not None:
             return y
@@ -491,7 +504,7 @@ class _ConcatLinear(torch.autograd.Function):
         rows, M = g.numel() // g.shape[-1], g.shape[-1]
 
         def dinput(wpart):                 # g @ W[:, part]: the k-major token GEMM reads the column range in place
-            d = token_gemm(g, wpart, True) if _token_gemm_pays(rows, wpart.shape[1], M) else None
+            d = token_gemm(g, wpart, True) if _token_gemm_pays(rows, wpart.shape[1], M, g.dtype) else None
             return torch.matmul(g, wpart) if d is None else d
         dx = dinput(w[:, :C1]) if ctx.needs_input_grad[0] else None
         dskip = dinput(w[:, C1:]) if ctx.needs_input_grad[1] else None

@@ -473,21 +473,27 @@ def test_colsum_matches_fp64(rows, M, ldx, dtype):
 
 @pytest.mark.parametrize("T,N,K1,K2,bias", [(3136, 96, 96, 96, True), (777, 192, 192, 192, True), (130, 384, 384, 384, False),
                                             (1000, 104, 64, 40, True), (257, 96, 264, 0, True), (64, 8, 8, 0, True)])
-def test_token_gemm_cat(T, N, K1, K2, bias):
-    """[a | a2] @ w.T + bias (the decoder's concat Linear, mamba_sys.py:835, and a plain biased Linear with a2 = None) in
-    bf16 against an fp64 product of the same bf16 values + the fp32 bias: result rounded once."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_token_gemm_cat(T, N, K1, K2, bias, dtype):
+    """[a | a2] @ w.T + bias (the decoder's concat Linear, mamba_sys.py:835, and a plain biased Linear with a2 = None)
+    against an fp64 product of the same stored values + the fp32 bias: bf16 -- result rounded once; fp32 (three-way bf16
+    split, six MFMAs per product) -- an fp32 GEMM's accuracy."""
     from mamba_unet_amd.ss2d_ops import token_gemm_cat
     gen = torch.Generator().manual_seed(T + N + K1 + K2)
-    a = torch.randn(T, K1, generator=gen).to(torch.bfloat16)
-    a2 = torch.randn(T, K2, generator=gen).to(torch.bfloat16) if K2 else None
-    w = (torch.randn(N, K1 + K2, generator=gen) * 0.2).to(torch.bfloat16)
+    a = torch.randn(T, K1, generator=gen).to(dtype)
+    a2 = torch.randn(T, K2, generator=gen).to(dtype) if K2 else None
+    w = (torch.randn(N, K1 + K2, generator=gen) * 0.2).to(dtype)
     b = torch.randn(N, generator=gen) if bias else None
     got = token_gemm_cat(a.cuda(), None if a2 is None else a2.cuda(), w.cuda(), None if b is None else b.cuda())
-    assert got is not None and got.shape == (T, N) and got.dtype == torch.bfloat16
+    assert got is not None and got.shape == (T, N) and got.dtype == dtype
     full = a.double() if a2 is None else torch.cat([a.double(), a2.double()], -1)
     want = full @ w.double().t() + (0 if b is None else b.double())
-    assert rel_l2(got.float().cpu(), want) < 4e-3
-    assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    if dtype == torch.bfloat16:
+        assert rel_l2(got.float().cpu(), want) < 4e-3
+        assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    else:
+        assert rel_l2(got.cpu(), want) < 2e-6
+        assert (got.cpu() - want).abs().max() <= 2.0 ** -19 * want.abs().max()
     if K2:   # K1 must be a multiple of the kernel's k chunk: anything else is refused, not computed wrongly
         assert token_gemm_cat(a.cuda()[:, :K1 - 8].contiguous(), a2.cuda(), w.cuda()[:, 8:].contiguous(), None) is None
 
@@ -537,46 +543,75 @@ def test_chan_wgrad_mfma(B, G, M, N, L, dtype):
 
 
 @pytest.mark.parametrize("B,G,M,K,L", [(3, 2, 76, 192, 3136), (2, 2, 192, 76, 784), (2, 4, 6, 192, 784), (3, 4, 768, 24, 196),
-                                       (2, 2, 112, 768, 196), (1, 1, 97, 65, 132), (2, 3, 33, 7, 12)])
-def test_chan_gemm_mfma(B, G, M, K, L):
-    """Y[b, g] = W[g] @ X[b, g] for a channel-major bf16 X taken as a row range of a wider block (like the dts rows of
-    x_dbl): x_proj / dt_proj and their input gradients, against an fp64 product of the same bf16 values."""
+                                       (2, 2, 112, 768, 196), (1, 1, 97, 65, 132), (2, 3, 33, 7, 12), (2, 4, 48, 1536, 52)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_chan_gemm_mfma(B, G, M, K, L, dtype):
+    """Y[b, g] = W[g] @ X[b, g] for a channel-major X taken as a row range of a wider block (like the dts rows of x_dbl):
+    x_proj / dt_proj and their input gradients, against an fp64 product of the same stored values.  fp32: three-way bf16
+    split on the MFMA, the accuracy of an fp32 GEMM; 1, 2 or 3 row tiles per workgroup by M."""
     from mamba_unet_amd.ss2d_ops import chan_gemm
     gen = torch.Generator().manual_seed(M * 7 + K + L)
-    W = (torch.randn(G, M, K, generator=gen) * 0.2).to(torch.bfloat16)
-    Xw = torch.randn(B, G, K + 8, L, generator=gen).to(torch.bfloat16)
+    W = (torch.randn(G, M, K, generator=gen) * 0.2).to(dtype)
+    Xw = torch.randn(B, G, K + 8, L, generator=gen).to(dtype)
     Xd = Xw.cuda()[:, :, 4:4 + K]
+    guard = torch.full((B * G * M + 2, L), 7.0, dtype=dtype, device="cuda")             # nothing may be written around the result
     got = chan_gemm(W.cuda(), Xd)
-    assert got is not None and got.shape == (B, G, M, L) and got.dtype == torch.bfloat16
+    assert got is not None and got.shape == (B, G, M, L) and got.dtype == dtype
     want = torch.matmul(W.double().unsqueeze(0), Xw[:, :, 4:4 + K].double())
-    assert rel_l2(got.float().cpu(), want) < 4e-3                     # bf16 rounding of the result only
-    assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
-    assert chan_gemm(W.cuda().float(), Xd.float()) is None              # fp32: library
+    if dtype == torch.bfloat16:
+        assert rel_l2(got.float().cpu(), want) < 4e-3                 # bf16 rounding of the result only
+        assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    else:
+        assert rel_l2(got.cpu(), want) < 2e-6
+        assert (got.cpu() - want).abs().max() <= 2.0 ** -19 * want.abs().max()
+    assert bool((guard == 7.0).all())
+    assert chan_gemm(W.cuda().half(), Xd.half()) is None                # other dtypes: library
 
 
 @pytest.mark.parametrize("T,N,K", [(3136, 384, 96), (3136, 96, 192), (777, 192, 384), (130, 1536, 768), (49, 768, 1536), (1, 8, 8),
                                    (1000, 104, 40), (257, 96, 264)])
 @pytest.mark.parametrize("k_major", [False, True])
-def test_token_gemm_mfma(T, N, K, k_major):
-    """The token-major Linear forward (a @ w.T) and input gradient (a @ w) of in_proj / out_proj / merge / expand in bf16
-    against an fp64 product of the same bf16 values: whole and ragged token tiles, column tiles and k chunks, both chunk
-    sizes, a row range of a wider buffer as the token operand."""
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_token_gemm_mfma(T, N, K, k_major, dtype):
+    """The token-major Linear forward (a @ w.T) and input gradient (a @ w) of in_proj / out_proj / merge / expand against an
+    fp64 product of the same stored values: whole and ragged token tiles, column tiles and k chunks, both chunk sizes, a row
+    range of a wider buffer as the token operand.  bf16: the result is rounded once.  fp32: every value enters the bf16 MFMA
+    as the exact sum of three bf16 values, six products kept -- the accuracy of an fp32 GEMM."""
     from mamba_unet_amd.ss2d_ops import token_gemm
     gen = torch.Generator().manual_seed(T + 3 * N + 5 * K + int(k_major))
-    a_wide = torch.randn(T, K + 16, generator=gen).to(torch.bfloat16)
-    w = (torch.randn(*((K, N) if k_major else (N, K)), generator=gen) * 0.2).to(torch.bfloat16)
+    a_wide = torch.randn(T, K + 16, generator=gen).to(dtype)
+    w = (torch.randn(*((K, N) if k_major else (N, K)), generator=gen) * 0.2).to(dtype)
     a = a_wide.cuda()[:, 8:8 + K]
-    guard = torch.full((T + 2, N), 7.0, dtype=torch.bfloat16, device="cuda")            # nothing may be written around the result
+    guard = torch.full((T + 2, N), 7.0, dtype=dtype, device="cuda")                     # nothing may be written around the result
     got = token_gemm(a, w.cuda(), k_major)
-    assert got is not None and got.shape == (T, N) and got.dtype == torch.bfloat16
+    assert got is not None and got.shape == (T, N) and got.dtype == dtype
     want = a_wide[:, 8:8 + K].double() @ (w.double() if k_major else w.double().t())
-    assert rel_l2(got.float().cpu(), want) < 4e-3                     # bf16 rounding of the result only
-    assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    if dtype == torch.bfloat16:
+        assert rel_l2(got.float().cpu(), want) < 4e-3                 # bf16 rounding of the result only
+        assert (got.float().cpu() - want).abs().max() <= 2.0 ** -8 * want.abs().max() + 1e-6
+    else:
+        assert rel_l2(got.cpu(), want) < 2e-6
+        assert (got.cpu() - want).abs().max() <= 2.0 ** -19 * want.abs().max()
     assert bool((guard == 7.0).all())
-    assert token_gemm(a.float(), w.cuda().float(), k_major) is None     # fp32: library
+    assert token_gemm(a, w.cuda().to(torch.float16), k_major) is None   # mixed / other dtypes: library
     a3 = a.reshape(1, T, K)                                             # leading batch axes are flattened
     got3 = token_gemm(a3, w.cuda(), k_major)
     assert got3.shape == (1, T, N) and torch.equal(got3[0], got)
+
+
+@pytest.mark.parametrize("scale", [1e-30, 1.0, 1e30])
+def test_token_gemm_fp32_split_is_scale_free(scale):
+    """The three-way split is by bits, not by magnitude: the same product at 1e-30, 1 and 1e30 times the operands (results
+    1e-30 ... 1e30 around 1) keeps the fp32-GEMM accuracy; zeros stay zeros."""
+    from mamba_unet_amd.ss2d_ops import token_gemm
+    gen = torch.Generator().manual_seed(5)
+    a = torch.randn(300, 64, generator=gen) * scale
+    a[:, 7] = 0.0
+    w = torch.randn(40, 64, generator=gen) / scale
+    got = token_gemm(a.cuda(), w.cuda(), False)
+    assert rel_l2(got.cpu(), a.double() @ w.double().t()) < 2e-6
+    z = token_gemm(torch.zeros(300, 64, device="cuda"), w.cuda(), False)
+    assert bool((z == 0).all())
 
 
 def test_linear_function_bf16():
@@ -600,7 +635,8 @@ def test_linear_function_bf16():
 def test_linear_function_keeps_its_bias(bias_dtype, autocast):
     """A biased Linear through ss2d_ops.linear: a pure-bf16 module (model.bfloat16(), no autocast: bf16 bias) must not lose
     its bias on the way to the own kernel (whose bias input is fp32); fp32 master parameters under autocast take the own
-    kernel with the bias; an fp32 module without autocast goes to the library.  All against F.linear in fp64."""
+    kernel with the bias; an fp32 module without autocast takes the fp32 kernel or the library by shape.  All against F.linear
+    in fp64."""
     from mamba_unet_amd import ss2d_ops
     gen = torch.Generator().manual_seed(12)
     pdt = bias_dtype

@@ -3,7 +3,10 @@
 times from a rocprofv3 trace.  On the GPU box:
     cd /tmp && rocprofv3 --kernel-trace --output-format csv -d $REPO/gpurun_out/cg -o cg -- python3 $REPO/tools/chan_gemm_bench.py
     python3 $REPO/tools/chan_gemm_bench.py --parse $REPO/gpurun_out/cg
-The run interleaves (own, library) for the four products at stages 0-2, six times; --parse prints the last repetition."""
+The run interleaves (own, library) for the four products at stages 0-2, six times; --parse prints the last repetition.
+    python3 tools/chan_gemm_bench.py --events [fp32]
+times the same products with HIP events instead (whole calls: the library's copies included) and prints the relative L2
+error of both against fp64."""
 import sys, os
 if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     import csv, glob
@@ -19,8 +22,29 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
     sys.exit(0)
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from mamba_unet_amd.ss2d_ops import chan_gemm
-dt = torch.bfloat16
+from mamba_unet_amd.ss2d_ops import chan_gemm, chan_wgrad
+dt = torch.float32 if sys.argv[-1] == "fp32" else torch.bfloat16
+EVENTS = len(sys.argv) > 1 and sys.argv[1] == "--events"
+
+
+def timed(fn, reps=30):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def rel(y, w_, x_):
+    ref = torch.matmul(w_[None, :1].double(), x_[:2, :1].double())
+    return float((y[:2, :1].double() - ref).norm() / ref.norm())
+
+
 for (C, H) in ((96, 56), (192, 28), (384, 14)):
     B, D, L, R = 24, 2 * C, H * H, (C + 15) // 16
     Cx = R + 32
@@ -28,6 +52,22 @@ for (C, H) in ((96, 56), (192, 28), (384, 14)):
     g = torch.randn(B, 2, 2 * Cx, L, device='cuda', dtype=dt); wt = w.transpose(1, 2).contiguous()
     dd = torch.randn(B, 4, D, L, device='cuda', dtype=dt); wd = torch.randn(4, D, R, device='cuda', dtype=dt); wdt = wd.transpose(1, 2).contiguous()
     xd = torch.randn(B, 4, Cx, L, device='cuda', dtype=dt)
+    if EVENTS:
+        cases = [("xproj fwd", w, xs2), ("xproj dX", wt, g), ("dt d_dts", wdt, dd), ("dt fwd", wd, xd[:, :, :R])]
+        print("stage C=%d L=%d  " % (C, L) + "  ".join("%s %.1f (lib %.1f) err %.1e (lib %.1e)" % (
+            n, timed(lambda: chan_gemm(w_, x_)), timed(lambda: torch.matmul(w_.unsqueeze(0), x_)),
+            rel(chan_gemm(w_, x_), w_, x_), rel(torch.matmul(w_.unsqueeze(0), x_), w_, x_)) for n, w_, x_ in cases))
+        def lib_w(P, Q):
+            return torch.matmul(P, Q.transpose(2, 3)).sum(0, dtype=torch.float32)
+
+        def relw(y, P, Q):
+            ref = torch.einsum("bml,bnl->mn", P[:, 0].double(), Q[:, 0].double())
+            return float((y[0].double() - ref).norm() / ref.norm())
+        wc = [("xproj dW", g, xs2), ("dt dW", dd, xd[:, :, :R])]
+        print("                   " + "  ".join("%s %.1f (lib %.1f) err %.1e (lib %.1e)" % (
+            n, timed(lambda: chan_wgrad(P, Q)), timed(lambda: lib_w(P, Q)), relw(chan_wgrad(P, Q), P, Q), relw(lib_w(P, Q), P, Q))
+            for n, P, Q in wc))
+        continue
     for it in range(6):
         a = chan_gemm(w, xs2); b_ = torch.matmul(w.unsqueeze(0), xs2)
         c = chan_gemm(wt, g); d = torch.matmul(wt.unsqueeze(0), g)

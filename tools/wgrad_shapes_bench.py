@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """The weight-gradient kernel (ss2d_linear_wgrad, bf16) at the Linear shapes of MambaUNet, batch 24: run under
-rocprofv3 --kernel-trace --output-format csv -d DIR -o w, then --parse DIR prints time and bytes/time per shape."""
+rocprofv3 --kernel-trace --output-format csv -d DIR -o w, then --parse DIR prints time and bytes/time per shape.
+    python3 tools/wgrad_shapes_bench.py --events [fp32]
+times whole calls with HIP events beside the library's g^T x, with the relative L2 error of both against fp64."""
 import os, sys
 SHAPES = []
 for s in range(4):
@@ -24,6 +26,27 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mamba_unet_amd.ss2d_ops import linear_wgrad  # noqa: E402
+if len(sys.argv) > 1 and sys.argv[1] == "--events":
+    dt = torch.float32 if sys.argv[-1] == "fp32" else torch.bfloat16
+
+    def timed(fn, reps=30):
+        for _ in range(3):
+            fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps * 1e3
+    for name, T, M, N in SHAPES:
+        g = torch.randn(T, M, device="cuda").to(dt); x = torch.randn(T, N, device="cuda").to(dt)
+        ref = g.double().t() @ x.double()
+        rel = lambda y: float((y.double() - ref).norm() / ref.norm())  # noqa: E731
+        print("%-22s T %6d M %5d N %5d  own %7.1f us  lib %7.1f us   err own %.1e lib %.1e" % (
+            name, T, M, N, timed(lambda: linear_wgrad(g, x)), timed(lambda: g.t() @ x), rel(linear_wgrad(g, x)), rel(g.t() @ x)))
+    sys.exit(0)
 for name, T, M, N in SHAPES:
     g = torch.randn(T, M, device="cuda").bfloat16(); x = torch.randn(T, N, device="cuda").bfloat16()
     for _ in range(REPS):
