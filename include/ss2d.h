@@ -221,7 +221,9 @@ int ss2d_xdbl_grad_pack(int dtype, const void *d_dts, const float *dB, const flo
  * reference gets it from autograd of nn.Linear): C[m][n] += sum_r A[r][m] * B[r][n] with A = dL/d(output)
  * (rows x M, row stride lda), B = the Linear's input (rows x N, row stride ldb), rows = batch*H*W tokens,
  * C = dL/dweight (M x N fp32, row stride ldc), ACCUMULATED INTO with float atomics: caller zero-fills.
- * fp32 MFMA (v_mfma_f32_32x32x2_f32); bf16 operands are widened exactly, products and sums stay fp32. */
+ * Products and sums are fp32 in both storage types: bf16 products are exact on v_mfma_f32_32x32x16_bf16; fp32 operands
+ * enter the same instruction as exact three-way bf16 splits, six products each (16-byte aligned rows), or
+ * v_mfma_f32_32x32x2_f32 for other layouts. */
 int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float *C, long long rows, int M, int N, int lda,
                       int ldb, int ldc, void *stream);
 
@@ -294,34 +296,37 @@ int ss2d_ln_head_bwd(int in_dtype, int out_dtype, const void *dlogits, const voi
 /* Weight gradients of x_proj (mamba_sys.py:407) and dt_proj (:420), whose operands are channel-major (rows = channels,
  * positions contiguous):  out[g*sog + i*soi + j*soj] += sum_b sum_l P[b*spb + g*spg + i*L + l] * Q[b*sqb + g*sqg + j*L + l]
  * for i < Mb (the wide operand), j < Ns; P, Q in dtype, out fp32 ACCUMULATED INTO (caller zero-fills; float atomics).
- * L, the strides and the base addresses must be multiples of 4 elements.  MFMA (bf16: exact products, fp32 sums). */
+ * L, the strides and the base addresses must be multiples of 4 elements.  MFMA (bf16: exact products, fp32 sums; fp32
+ * operands as exact three-way bf16 splits, six products each). */
 int ss2d_chan_wgrad(int dtype, const void *P, const void *Q, float *out, int B, int G, int Mb, int Ns, int L, long long spb,
                     long long spg, long long sqb, long long sqg, long long sog, long long soi, long long soj, void *stream);
 
 /* x_proj (mamba_sys.py:407), dt_proj (:420) and their input gradients as ONE product over channel-major operands:
  *   Y[b*syb + g*syg + m*L + l] = sum_{k<K} W[g*swg + m*ldw + k] * X[b*sxb + g*sxg + k*L + l],   m < M, l < L
  * (x_proj: W = x_proj_weight, X = xs; its dX: W = weight^T, X = d_x_dbl; dt_proj: W = dt_projs_weight, X = the dts rows of
- * x_dbl; its d_dts: W = weight^T, X = d_delta).  bf16 in, fp32 accumulation (MFMA), bf16 out, Y WRITTEN.  X and Y rows are L
- * apart and may be row ranges of wider blocks (strides).  L, the strides of X / Y and their base addresses must be
- * multiples of 4 elements; ldw >= K and the group stride swg multiples of 8, W 16-byte aligned, and the columns
- * K .. ldw-1 of W must hold zeros.  SS2D_DTYPE_BF16 only (fp32 callers use the BLAS library). */
+ * x_dbl; its d_dts: W = weight^T, X = d_delta).  W, X, Y in dtype, fp32 accumulation on the bf16 MFMA (fp32 operands enter
+ * it as exact three-way bf16 splits, six products each: an fp32 GEMM's accuracy), Y WRITTEN.  X and Y rows are L apart and
+ * may be row ranges of wider blocks (strides).  L, the strides of X / Y and their base addresses must be multiples of 4
+ * elements (fp32: X, Y 16-byte aligned); ldw >= K and the group stride swg multiples of 8 (fp32: 4), W 16-byte aligned,
+ * and the columns K .. ldw-1 of W must hold zeros. */
 int ss2d_chan_gemm(int dtype, const void *W, const void *X, void *Y, int B, int G, int M, int K, int ldw, int L, long long swg,
                    long long sxb, long long sxg, long long syb, long long syg, void *stream);
 
 /* The token-major Linears (in_proj / out_proj, mamba_sys.py:298, :337, applied :556, :563; PatchMerging2D.reduction :196,
- * the expand Linears :243, :261), bf16 on MFMA:
+ * the expand Linears :243, :261) on the bf16 MFMA; A, B, C in dtype (bf16, or fp32 as exact three-way bf16 splits with six
+ * products each -- an fp32 GEMM's accuracy):
  *   b_k_major = 0:  C[t*ldc + n] = sum_k A[t*lda + k] * B[n*ldb + k]     (F.linear(x, weight): A = x, B = weight (out, in))
  *   b_k_major = 1:  C[t*ldc + n] = sum_k A[t*lda + k] * B[k*ldb + n]     (its input gradient: A = dy, B = weight)
- * t < T, n < N; fp32 accumulation, C WRITTEN in bf16.  N, K and the leading dimensions multiples of 8, operands 16-byte
- * aligned.  SS2D_DTYPE_BF16 only (fp32 callers use the BLAS library). */
+ * t < T, n < N; fp32 accumulation, C WRITTEN.  N, K and the leading dimensions multiples of 8 (fp32: 4), operands 16-byte
+ * aligned. */
 int ss2d_token_gemm(int dtype, const void *A, const void *B, void *C, long long T, int N, int K, int lda, int ldb, int ldc,
                     int b_k_major, void *stream);
 /* The same forward product over a CONCATENATED input, without the concatenation, and with the bias:
  *   C (T x N) = [A | A2] (T x (K1 + K2)) * W^T + bias      W (N x K) row-major with leading dimension ldw, K = K1 + K2
  * -- `self.concat_back_dim[inx](torch.cat([x, x_downsample[3 - inx]], -1))` (mamba_sys.py:835, the nn.Linear(2*dim, dim) of
- * :774-778).  bias (N) fp32 is added before the result is rounded to bf16; nullable.  A2 may be null with K1 == K (a plain
- * biased Linear).  K1 must be a multiple of the kernel's k chunk (32 for K <= 256, else 64); the other conditions are those
- * of ss2d_token_gemm. */
+ * :774-778).  bias (N) fp32 is added before the result is rounded / stored; nullable.  A2 may be null with K1 == K (a plain
+ * biased Linear).  K1 must be a multiple of the kernel's k chunk (bf16: 32 for K <= 256, else 64; fp32: 32); the other
+ * conditions are those of ss2d_token_gemm. */
 int ss2d_token_gemm_cat(int dtype, const void *A, const void *A2, const void *W, const float *bias, void *C, long long T, int N,
                         int K, int K1, int lda, int lda2, int ldw, int ldc, void *stream);
 

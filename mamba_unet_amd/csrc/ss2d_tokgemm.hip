@@ -186,7 +186,7 @@ constexpr int FCROW = 4 * GN + 16;                        // result image [128 t
 constexpr int flds(bool kmajor) { return 2 * fstage(kmajor) > GT * FCROW ? 2 * fstage(kmajor) : GT * FCROW; }
 
 template <bool B_KMAJOR>
-__global__ __launch_bounds__(256) void tok_gemm_f32_kernel(const TgParamsF p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void tok_gemm_f32_kernel(const TgParamsF p) {
     constexpr int IMG_B = fimg_b(B_KMAJOR), STAGE = fstage(B_KMAJOR), BROW = B_KMAJOR ? BROW_NN : FROW;
     __shared__ __align__(16) unsigned char lds[flds(B_KMAJOR)];
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, half = lane >> 5;
