@@ -311,6 +311,48 @@ __device__ __forceinline__ void buf_store2m(__amdgpu_buffer_rsrc_t rs, int pos, 
         }
     }
 }
+// The same two accesses for a block of SEVERAL rows behind one descriptor (num_records = the whole block, base = its first
+// row) with the row chosen by a scalar byte offset `soff`: gfx950 includes the scalar offset in the range check (an access
+// is dropped when voffset >= num_records - soffset: tools/ubench/soffset_check.hip), so the descriptor cannot be one row
+// long, and positions past the row end are pushed out of range explicitly.  The block must be shorter than 2^31 bytes.
+constexpr int SS2D_BUF_OOR = 0x7ffffff0;   // + any soff < 2^31 stays a 32-bit offset beyond every such block
+template <bool VEC, typename IO>
+__device__ __forceinline__ f2 buf_load2s(__amdgpu_buffer_rsrc_t rs, int pos, int L, bool rev, int soff) {
+    constexpr bool F32 = sizeof(IO) == 4;
+    if (VEC) {
+        const int off = pos < L ? (rev ? L - 2 - pos : pos) * (int)sizeof(IO) : SS2D_BUF_OOR;
+        f2 t;
+        if (F32) t = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, soff, 0));
+        else t = bf16pair_to_f2(__builtin_amdgcn_raw_buffer_load_b32(rs, off, soff, 0));
+        return rev ? f2{t.y, t.x} : t;
+    }
+    f2 r;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int off = pos + e < L ? (rev ? L - 1 - pos - e : pos + e) * (int)sizeof(IO) : SS2D_BUF_OOR;
+        if (F32) r[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, soff, 0));
+        else r[e] = __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_raw_buffer_load_b16(rs, off, soff, 0) << 16);
+    }
+    return r;
+}
+template <bool VEC, typename IO>
+__device__ __forceinline__ void buf_store2s(__amdgpu_buffer_rsrc_t rs, int pos, int L, bool rev, f2 v, int soff) {
+    constexpr bool F32 = sizeof(IO) == 4;
+    if (VEC) {
+        const int off = pos < L ? (rev ? L - 2 - pos : pos) * (int)sizeof(IO) : SS2D_BUF_OOR;
+        const f2 w = rev ? f2{v.y, v.x} : v;
+        if (F32) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), rs, off, soff, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_convertvector(w, bf16x2)), rs, off, soff, 0);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int off = pos + e < L ? (rev ? L - 1 - pos - e : pos + e) * (int)sizeof(IO) : SS2D_BUF_OOR;
+            const float ve = v[e];   // a copy (see buf_store2m)
+            if (F32) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ve), rs, off, soff, 0);
+            else __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(unsigned short, (bf16)ve), rs, off, soff, 0);
+        }
+    }
+}
 // 4 consecutive scan positions pos..pos+3 (pos % 4 == 0) of row `row_elems`-th element on inside the block behind `rs`
 template <bool VEC, typename IO>
 __device__ __forceinline__ f4 buf_load4m(__amdgpu_buffer_rsrc_t rs, unsigned row_off, int pos, int L, bool rev) {

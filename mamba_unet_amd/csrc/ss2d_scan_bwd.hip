@@ -507,7 +507,8 @@ static int scan_bwd_impl(int dtype, const void *u, const void *delta, const floa
         return -7;
     }
     // the SS2D call pattern: 16 states, no gate -> state-row kernel (SS2D_BWD_KERNEL=general keeps the general one: A/B runs)
-    if (dstate == 16 && z == nullptr && !force_general_kernel() && ((((uintptr_t)A | (uintptr_t)ckpt) & 15) == 0)) {
+    // (L <= 2^22: the state-row kernel addresses the <= 96 rows of a part through one descriptor of less than 2^31 bytes)
+    if (dstate == 16 && z == nullptr && !force_general_kernel() && L <= (1 << 22) && ((((uintptr_t)A | (uintptr_t)ckpt) & 15) == 0)) {
         const int rc = ss2d_scan_bwd_sr_launch(dtype, p, vec4, dirs, static_cast<float *>(workspace), workspace_bytes, s);
         if (rc) ss2d_set_error("selective_scan_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
         return rc;

@@ -140,11 +140,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         float nw[NR];                                  // DTR: dt_proj weight row of the next channel (wave-uniform: scalar registers)
         f2 dtsv[NR];                                   // DTR: dts[r] at this lane's two positions of the current chunk
         typedef const float __attribute__((address_space(4))) *cfp;
+        // One descriptor per tensor and part (base = the part's first row, num_records = the part's rows) and a scalar byte
+        // offset per channel, so that the channel loop builds no descriptors (seven per channel-chunk were 0.18 scalar
+        // instructions per vector instruction, with two waves per SIMD to hide them behind).  The scalar offset is part
+        // of the hardware's range check, so a descriptor cannot be one row long: positions past the row end are sent out
+        // of range by the vector offset instead (buf_load2s / buf_store2s).
+        constexpr int NR_ = DTR > 0 ? DTR : 1;
+        const unsigned partbytes = (unsigned)n * rowbytes;
+        const __amdgpu_buffer_rsrc_t rsU = make_rsrc(static_cast<const IO *>(p.u) + urow0 * (size_t)L, partbytes);
+        const __amdgpu_buffer_rsrc_t rsY = make_rsrc(static_cast<const IO *>(p.dout) + urow0 * (size_t)L, partbytes);
+        const __amdgpu_buffer_rsrc_t rsDl = make_rsrc(static_cast<const IO *>(p.delta) + (DTR > 0 ? (size_t)bg * bcs : r0 * (size_t)L),
+                                                      DTR > 0 ? (unsigned)NR_ * rowbytes : partbytes);
+        const __amdgpu_buffer_rsrc_t rsDu = make_rsrc(static_cast<IO *>(p.du) + r0 * (size_t)L, partbytes);
+        const __amdgpu_buffer_rsrc_t rsDd = make_rsrc(static_cast<IO *>(p.ddelta) + r0 * (size_t)L, partbytes);
+        const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A + (size_t)cdim0 * 16, 64u * n);
+        const __amdgpu_buffer_rsrc_t rsCk = make_rsrc(p.ckpt + r0 * (size_t)nchunks * 16, 64u * n * nchunks);
+        const __amdgpu_buffer_rsrc_t rsBi = make_rsrc(biasp + cdim0, 4u * n);
+        const __amdgpu_buffer_rsrc_t rsDp = make_rsrc(Dp + cdim0, 4u * n);
         auto input_load = [&](int k_, int chunk_) {
             const int ps_ = chunk_ * CHUNK + 8 * seg + 2 * row;
-            nu = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.u) + (urow0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
-            if (DTR == 0) nd = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.delta) + (r0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
-            ny = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.dout) + (urow0 + k_) * (size_t)L, rowbytes), ps_, L, rev);
+            const int so_ = k_ * (int)rowbytes;
+            nu = buf_load2s<VEC, IO>(rsU, ps_, L, rev, so_);
+            if (DTR == 0) nd = buf_load2s<VEC, IO>(rsDl, ps_, L, rev, so_);
+            ny = buf_load2s<VEC, IO>(rsY, ps_, L, rev, so_);
             if (DTR > 0) {
                 const cfp wp = (cfp)(uintptr_t)(p.dtw + (size_t)(cdim0 + k_) * DTR);
 #pragma unroll
@@ -156,15 +174,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const int ps_ = chunk_ * CHUNK + 8 * seg + 2 * row;
 #pragma unroll
                 for (int r = 0; r < NR; ++r)
-                    dtsv[r] = buf_load2m<VEC, IO>(make_rsrc(static_cast<const IO *>(p.delta) + (size_t)bg * bcs + (size_t)r * L, rowbytes), ps_, L, rev);
+                    dtsv[r] = buf_load2s<VEC, IO>(rsDl, ps_, L, rev, r * (int)rowbytes);
             }
         };
         auto param_load = [&](int k_, int chunk_) {
-            const int c_ = cdim0 + k_;
-            nAv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.A + (size_t)c_ * 16, 64), 16 * row, 0, 0));
-            nck = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(make_rsrc(p.ckpt + ((r0 + k_) * nchunks + chunk_) * 16, 64), 16 * row, 0, 0));
-            nbias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(biasp + c_, 4), 0, 0, 0));
-            nD = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(make_rsrc(Dp + c_, 4), 0, 0, 0));
+            nAv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsA, 16 * row, 64 * k_, 0));
+            nck = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsCk, 16 * row, 64 * (k_ * nchunks + chunk_), 0));
+            nbias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsBi, 0, 4 * k_, 0));
+            nD = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDp, 0, 4 * k_, 0));
         };
         f4 tlo[NM], thi[NM];
         tile_load(nchunks - 1, tlo, thi);
@@ -358,9 +375,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (p.softplus) { ddta *= sg0; ddtb *= sg1; }
                 ddta = ok0 ? ddta : 0.0f;
                 ddtb = ok1 ? ddtb : 0.0f;
-                buf_store2m<VEC, IO>(make_rsrc(static_cast<IO *>(p.du) + (r0 + k) * (size_t)L, rowbytes), ps, L, rev,
-                                     f2{e0 * dtq.x + dyq.x * Dc, o0 * dtq.y + dyq.y * Dc});
-                buf_store2m<VEC, IO>(make_rsrc(static_cast<IO *>(p.ddelta) + (r0 + k) * (size_t)L, rowbytes), ps, L, rev, f2{ddta, ddtb});
+                buf_store2s<VEC, IO>(rsDu, ps, L, rev, f2{e0 * dtq.x + dyq.x * Dc, o0 * dtq.y + dyq.y * Dc}, k * (int)rowbytes);
+                buf_store2s<VEC, IO>(rsDd, ps, L, rev, f2{ddta, ddtb}, k * (int)rowbytes);
                 SR_PROBE(13);
                 // ---- dA (4 states of this row), dD, ddelta_bias: row sums, accumulated over the chunks in the wave's LDS record
                 float s0 = dAp[0].x, s1 = dAp[0].y, s2 = dAp[1].x, s3 = dAp[1].y, sD = dyq.x * u0 + dyq.y * u1, sb = ddta + ddtb;
