@@ -326,30 +326,33 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p)
     const bf16 *__restrict__ B = static_cast<const bf16 *>(p.B);
     // this thread's pieces of a chunk: 4 of A (64 rows x 16 pieces), 3 of B (64 rows x 12 pieces)
     // TWO chunks are in flight in registers (set = stage = chunk parity): with one, every chunk waited a full memory round
-    // trip -- a workgroup is alone on its CU (about one per CU is launched) and the MFMAs of a chunk take a fraction of that
+    // trip -- a workgroup is alone on its CU (about one per CU is launched) and the MFMAs of a chunk take a fraction of that.
+    // The operands come through buffer descriptors that end with the slab (r1 rows): a row at or past the slab end reads
+    // zeros by the range check, and a column past M / N is sent out of range by its offset.  Nothing touches a loaded
+    // value before its ds_write: the first version zeroed those pieces with an AND on the value, the compiler gathered the
+    // ANDs of BOTH sets at the loop latch behind one s_waitcnt vmcnt(0), and every trip waited for the loads it had just
+    // issued (main loop 13-20 us whatever the shape).  The chunk's row offset is a scalar (soffset), so a chunk costs no
+    // address arithmetic at all.  (Host: (rows + 4 chunks) * ld * 2 bytes < 2^31.)
     u32x4 pa[2][4], pb[2][3];
-    int brow[3], bcol[3];
+    int brow[3], bcol[3], aofs[4], bofs[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) { const int id = j * 256 + tid; brow[j] = id / 12; bcol[j] = (id - brow[j] * 12) * 8; }
     const int arow = tid >> 4, acol = (tid & 15) * 8;          // piece j: row arow + 16 j
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (unsigned)(r1 > 0 ? r1 * p.lda * 2 : 0));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (unsigned)(r1 > 0 ? r1 * p.ldb * 2 : 0));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) aofs[j] = m0 + acol < p.M ? ((arow + 16 * j) * p.lda + m0 + acol) * 2 : SS2D_BUF_OOR;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) bofs[j] = n0 + bcol[j] < p.N ? (brow[j] * p.ldb + n0 + bcol[j]) * 2 : SS2D_BUF_OOR;
     constexpr std::integral_constant<int, 0> S0{};
     constexpr std::integral_constant<int, 1> S1{};
     auto load_chunk = [&](auto set, long long rc) {              // rows at or past r1 (also whole chunks) read as zeros
         constexpr int S = decltype(set)::value;
+        const int sa = (int)(rc * p.lda * 2), sb = (int)(rc * p.ldb * 2);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long long row = rc + arow + 16 * j;
-            const bool ok = row < r1 && m0 + acol < p.M;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(A + (ok ? row * p.lda + m0 + acol : 0));
-            pa[S][j] = v & (ok ? ~0u : 0u);
-        }
+        for (int j = 0; j < 4; ++j) pa[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aofs[j], sa, 0);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const long long row = rc + brow[j];
-            const bool ok = row < r1 && n0 + bcol[j] < p.N;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(B + (ok ? row * p.ldb + n0 + bcol[j] : 0));
-            pb[S][j] = v & (ok ? ~0u : 0u);
-        }
+        for (int j = 0; j < 3; ++j) pb[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, bofs[j], sb, 0);
     };
     auto put_chunk = [&](auto set) {
         constexpr int S = decltype(set)::value;
@@ -371,6 +374,9 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p)
     const int aoff = trow * TAROW + 64 * wave + tcol, boff = trow * TBROW + tcol;
     const bool live = m0 + 32 * wave < p.M;                     // a wave whose rows lie past M multiplies nothing
     const long long nchunks = r1 > r0 ? (r1 - r0 + TKC - 1) / TKC : 0;
+    // (Requesting the fragments of k-step ks + 1 ahead of the MFMAs of k-step ks changes nothing: a chunk costs 0.86 us
+    // because the 28 KB it pulls through L2 arrive at ~9 TB/s chip-wide, tools/wgrad_floor_probe.py -- every shape of the
+    // model moves the same 101 / 50 MB of tile operands, and its atomics cost about as much again.)
     auto products = [&](auto set) {
         constexpr int s = decltype(set)::value;
         if (live) {
@@ -391,7 +397,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p)
             }
         }
     };
-    if (nchunks > 0) { load_chunk(S0, r0); load_chunk(S1, r0 + TKC); }
+    // (the barrier keeps set 0's loads in front of set 1's: interleaved, the first put of every trip would wait for both)
+    if (nchunks > 0) { load_chunk(S0, r0); __builtin_amdgcn_sched_barrier(0); load_chunk(S1, r0 + TKC); }
     // two chunks per trip, nothing under a branch (an odd count ends with a chunk of zeros); a stage was last read two chunks
     // ago, behind the previous barrier
     for (long long c = 0; c < nchunks; c += 2) {
@@ -416,6 +423,14 @@ __global__ __launch_bounds__(256) void wgrad_bf16_tr_kernel(const WgradParams p)
                 if (m < p.M && n < p.N) atomicAdd(p.C + (size_t)m * p.ldc + n, acc[j][e]);
             }
         }
+    }
+#else   // keeps the products alive without the flush (a value that never occurs)
+    if (live && nchunks > 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (acc[j][e] == 1.2345e30f) atomicAdd(p.C, acc[j][e]);
     }
 #endif
 }
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_tr_kernel(const WgradParams p) 
     // flight in registers (set = stage = chunk parity)
     constexpr int NA = FTKC * 32 / 256, NB = (FTKC * 24 + 255) / 256;
     u32x4 pa[2][NA], pb[2][NB];
-    int brow[NB], bcol[NB];
+    int brow[NB], bcol[NB], aofs[NA], bofs[NB];
     bool bon[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -455,24 +470,23 @@ __global__ __launch_bounds__(256) void wgrad_f32_tr_kernel(const WgradParams p) 
         brow[j] = (bon[j] ? id : 0) / 24; bcol[j] = ((bon[j] ? id : 0) - brow[j] * 24) * 4;
     }
     const int arow = tid >> 5, acol = (tid & 31) * 4;          // piece j: row arow + 8 j
+    // operands through descriptors that end with the slab, columns past M / N sent out of range by their offset, the
+    // chunk's rows chosen by a scalar offset: see wgrad_bf16_tr_kernel
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(A, (unsigned)(r1 > 0 ? r1 * p.lda * 4 : 0));
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(B, (unsigned)(r1 > 0 ? r1 * p.ldb * 4 : 0));
+#pragma unroll
+    for (int j = 0; j < NA; ++j) aofs[j] = m0 + acol < p.M ? ((arow + 8 * j) * p.lda + m0 + acol) * 4 : SS2D_BUF_OOR;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) bofs[j] = (bon[j] && n0 + bcol[j] < p.N) ? (brow[j] * p.ldb + n0 + bcol[j]) * 4 : SS2D_BUF_OOR;
     constexpr std::integral_constant<int, 0> S0{};
     constexpr std::integral_constant<int, 1> S1{};
     auto load_chunk = [&](auto set, long long rc) {              // rows at or past r1 (also whole chunks) read as zeros
         constexpr int S = decltype(set)::value;
+        const int sa = (int)(rc * p.lda * 4), sb = (int)(rc * p.ldb * 4);
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const long long row = rc + arow + 8 * j;
-            const bool ok = row < r1 && m0 + acol < p.M;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(A + (ok ? row * p.lda + m0 + acol : 0));
-            pa[S][j] = v & (ok ? ~0u : 0u);
-        }
+        for (int j = 0; j < NA; ++j) pa[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsA, aofs[j], sa, 0);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const long long row = rc + brow[j];
-            const bool ok = bon[j] && row < r1 && n0 + bcol[j] < p.N;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(B + (ok ? row * p.ldb + n0 + bcol[j] : 0));
-            pb[S][j] = v & (ok ? ~0u : 0u);
-        }
+        for (int j = 0; j < NB; ++j) pb[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, bofs[j], sb, 0);
     };
     auto put_chunk = [&](auto set) {
         constexpr int S = decltype(set)::value;
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(256) void wgrad_f32_tr_kernel(const WgradParams p) 
             }
         }
     };
-    if (nchunks > 0) { load_chunk(S0, r0); load_chunk(S1, r0 + FTKC); }
+    if (nchunks > 0) { load_chunk(S0, r0); __builtin_amdgcn_sched_barrier(0); load_chunk(S1, r0 + FTKC); }
     for (long long c = 0; c < nchunks; c += 2) {                 // see wgrad_bf16_tr_kernel
         put_chunk(S0);
         load_chunk(S0, r0 + (c + 2) * FTKC);
@@ -576,8 +590,10 @@ extern "C" int ss2d_linear_wgrad(int dtype, const void *A, const void *B, float 
     static const bool env_widen = getenv("SS2D_WGRAD_WIDEN") != nullptr;     // A/B against the fp32-MFMA form, read once
     const int q16 = dtype == SS2D_DTYPE_BF16 ? 8 : 4;            // elements per 16 bytes
     // (fp32 with SS2D_WGRAD_WIDEN: the fp32-MFMA form, for A/B)
+    // (the LDS-staged kernels address their operands with 32-bit byte offsets: rows + 4 chunks of the widest operand < 2^31 bytes)
+    const long long widest = (rows + 4 * TKC) * (long long)(lda > ldb ? lda : ldb) * (dtype == SS2D_DTYPE_BF16 ? 2 : 4);
     const bool use_tr = !env_widen && !(env_direct && dtype == SS2D_DTYPE_BF16) && M % q16 == 0 && N % q16 == 0 && lda % q16 == 0 && ldb % q16 == 0 &&
-                        ((((uintptr_t)A | (uintptr_t)B) & 15) == 0);
+                        ((((uintptr_t)A | (uintptr_t)B) & 15) == 0) && widest < (1ll << 31);
     long long target_waves = 1024;
     static const long long env_waves = ss2d_env_ll("SS2D_WGRAD_WAVES", 0);   // tuning knob, read once
     if (env_waves >= 4 && env_waves <= 65536) target_waves = env_waves;
