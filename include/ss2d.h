@@ -211,6 +211,23 @@ int ss2d_scan_params_bwd(const float *A, const float *dA, const float *dD, const
                          float *dA_logs, float *dDs, float *ddt_bias, float *ddt_w, int K, int Dm, int N, int R,
                          int regroup, void *stream);
 
+/* Every parameter-derived operand of one fused-direction SS2D call (mamba_sys.py:407, :420, :428-431) in one launch
+ * each way: A, D, bias, w as ss2d_scan_params_fwd with K = 4, regroup = 1, and from x_w = x_proj_weight (4, Cx, Dm) fp32
+ * (Cx = R + 2N, reference direction order) and dt_w, in `dtype` with rows padded with zeros to their leading dimension
+ * (the operand layout of ss2d_chan_gemm):
+ *   xw  (2, 2Cx, ldD): xw[o][rev*Cx + c][d] = x_w[2*rev + o][c][d]    (x_proj forward: both directions of orientation o)
+ *   xwT (2, Dm, ldC):  xwT[o][d][rev*Cx + c] = the same element        (input gradient of x_proj)
+ *   dtwT (4, R, ldD):  dtwT[g][r][d] = dt_w[k(g)][d][r]                (d_dts = dt_w^T . ddelta)
+ *   dtw_io (4, Dm, ldR; nullable): dt_w[k(g)][d][r]                    (delta as a GEMM: ranks other than 6 / 12)
+ * _bwd: as ss2d_scan_params_bwd, plus dx_w (4, Cx, Dm) fp32 (reference order) from d_xw (2, 2Cx, Dm) fp32, the weight
+ * gradient of the stacked x_proj (null = zero).  Outputs are overwritten. */
+int ss2d_block_params_fwd(int dtype, const float *A_logs, const float *Ds, const float *dt_bias, const float *dt_w,
+                          const float *x_w, float *A, float *D, float *bias, float *w, void *xw, void *xwT, void *dtwT,
+                          void *dtw_io, int Dm, int N, int R, int ldD, int ldC, int ldR, void *stream);
+int ss2d_block_params_bwd(const float *A, const float *dA, const float *dD, const float *dbias, const float *dw,
+                          const float *d_xw, float *dA_logs, float *dDs, float *ddt_bias, float *ddt_w, float *dx_w,
+                          int Dm, int N, int R, void *stream);
+
 /* Gradient of the x_proj output x_dbl (batch, K, R + 2N, L) (mamba_sys.py:407-417; the autograd of its `torch.split`)
  * assembled in one pass: rows [0, R) of every (batch, k) block from d_dts (nblocks, R, L) in `dtype`, rows [R, R+N) and
  * [R+N, R+2N) from the scan backward's fp32 dB / dC (nblocks, N, L), cast to `dtype`.  nblocks = batch * K. */

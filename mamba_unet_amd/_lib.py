@@ -41,6 +41,8 @@ _SIGNATURES = {
     "ss2d_dt_proj_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_longlong, _vp]),
     "ss2d_scan_params_fwd": (_i, [_vp] * 8 + [_i, _i, _i, _i, _i, _vp]),
     "ss2d_scan_params_bwd": (_i, [_vp] * 9 + [_i, _i, _i, _i, _i, _vp]),
+    "ss2d_block_params_fwd": (_i, [_i] + [_vp] * 13 + [_i] * 6 + [_vp]),
+    "ss2d_block_params_bwd": (_i, [_vp] * 11 + [_i, _i, _i, _vp]),
     "ss2d_xdbl_grad_pack": (_i, [_i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp]),
     "ss2d_linear_wgrad": (_i, [_i, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _vp]),
     "ss2d_outnorm_gate_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, ctypes.c_float, _vp]),

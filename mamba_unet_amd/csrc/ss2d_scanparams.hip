@@ -78,6 +78,138 @@ extern "C" int ss2d_scan_params_bwd(const float *A, const float *dA, const float
     return run(true, p, stream, "scan_params_bwd");
 }
 
+// ---- every parameter-derived operand of one fused-direction SS2D call in ONE launch each way (mamba_sys.py:407, :420,
+// :428-431).  Besides the four outputs of scan_params (regrouped) the call needs the x_proj weight with the two directions
+// of an orientation stacked, that matrix transposed (input gradient of x_proj), the dt_proj weight transposed (d_dts) and,
+// for the ranks whose delta is a GEMM, the dt_proj weight itself -- all four in the activations' storage type with rows
+// padded with zeros to 16 bytes, the operand layout of ss2d_chan_gemm.  As torch ops these were a regrouping copy, a
+// cast, a transposing copy and a pad per operand and block, each a 4-5 us launch: ~90 launches per training step.
+namespace {
+
+struct BlockParamsArgs {
+    ScanParamsArgs sp;              // the scan_params part (K = 4, swap = 1)
+    const float *xw_src;            // fwd: x_proj_weight (4, Cx, Dm) fp32, reference order   bwd: d_xw (2, 2Cx, Dm) fp32
+    void *xw, *xwT, *dtwT, *dtwio;  // fwd outputs (IO type): (2, 2Cx, ldD), (2, Dm, ldC), (4, R, ldD), (4, Dm, ldR; nullable)
+    float *dxw;                     // bwd output: d x_proj_weight (4, Cx, Dm) fp32, reference order
+    int Cx, ldD, ldC, ldR;
+};
+
+template <typename IO, bool BWD>
+__global__ __launch_bounds__(256) void block_params_kernel(const BlockParamsArgs q) {
+    const ScanParamsArgs &p = q.sp;
+    const int Dm = p.Dm, R = p.R, Cx = q.Cx;
+    const long long n0 = (long long)4 * Dm * (p.N + 2 + R);
+    const long long n1 = BWD ? (long long)4 * Cx * Dm : (long long)2 * 2 * Cx * q.ldD;   // xw (bwd: d x_proj_weight)
+    const long long n2 = BWD ? 0 : (long long)2 * Dm * q.ldC;                              // xwT
+    const long long n3 = BWD ? 0 : (long long)4 * R * q.ldD;                               // dtwT
+    const long long n4 = (BWD || !q.dtwio) ? 0 : (long long)4 * Dm * q.ldR;                // dt weight in the IO type
+    const long long total = n0 + n1 + n2 + n3 + n4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        if (i < n0) {   // as scan_params_kernel
+            const int per_row = p.N + 2 + R;
+            const int e = (int)(i % per_row);
+            const long long row = i / per_row;
+            const int g = (int)(row / Dm), d = (int)(row % Dm);
+            const long long other = (long long)src_group(g, 1) * Dm + d;
+            if (e < p.N) {
+                if (!BWD) p.oa[row * p.N + e] = -expf(p.a[other * p.N + e]);
+                else p.oa[other * p.N + e] = p.a ? p.a[row * p.N + e] * p.A[row * p.N + e] : 0.0f;
+            } else if (e == p.N) {
+                if (!BWD) p.od[row] = p.d[other]; else p.od[other] = p.d ? p.d[row] : 0.0f;
+            } else if (e == p.N + 1) {
+                if (!BWD) p.ob[row] = p.b[other]; else p.ob[other] = p.b ? p.b[row] : 0.0f;
+            } else {
+                const int r = e - p.N - 2;
+                if (!BWD) p.ow[row * R + r] = p.w[other * R + r]; else p.ow[other * R + r] = p.w ? p.w[row * R + r] : 0.0f;
+            }
+            continue;
+        }
+        long long j = i - n0;
+        if (BWD) {      // d x_proj_weight[k = 2 rev + o][c][d] = d_xw[o][rev Cx + c][d]
+            const int d = (int)(j % Dm);
+            const long long rowk = j / Dm;
+            const int c = (int)(rowk % Cx), k = (int)(rowk / Cx), o = k & 1, rev = k >> 1;
+            q.dxw[j] = q.xw_src ? q.xw_src[((long long)o * 2 * Cx + rev * Cx + c) * Dm + d] : 0.0f;
+            continue;
+        }
+        if (j < n1) {   // xw[o][m = rev Cx + c][d], zero for d >= Dm
+            const int d = (int)(j % q.ldD);
+            const long long rowm = j / q.ldD;
+            const int m = (int)(rowm % (2 * Cx)), o = (int)(rowm / (2 * Cx)), rev = m / Cx, c = m - rev * Cx;
+            st1(static_cast<IO *>(q.xw) + j, d < Dm ? q.xw_src[((long long)(2 * rev + o) * Cx + c) * Dm + d] : 0.0f);
+            continue;
+        }
+        j -= n1;
+        if (j < n2) {   // xwT[o][d][m], zero for m >= 2 Cx
+            const int m = (int)(j % q.ldC);
+            const long long rowd = j / q.ldC;
+            const int d = (int)(rowd % Dm), o = (int)(rowd / Dm), rev = m / Cx, c = m - rev * Cx;
+            st1(static_cast<IO *>(q.xwT) + j, m < 2 * Cx ? q.xw_src[((long long)(2 * rev + o) * Cx + c) * Dm + d] : 0.0f);
+            continue;
+        }
+        j -= n2;
+        if (j < n3) {   // dtwT[g][r][d], zero for d >= Dm
+            const int d = (int)(j % q.ldD);
+            const long long rowr = j / q.ldD;
+            const int r = (int)(rowr % R), g = (int)(rowr / R);
+            st1(static_cast<IO *>(q.dtwT) + j, d < Dm ? p.w[((long long)src_group(g, 1) * Dm + d) * R + r] : 0.0f);
+            continue;
+        }
+        j -= n3;
+        {               // dt weight [g][d][r] in the IO type, zero for r >= R
+            const int r = (int)(j % q.ldR);
+            const long long row = j / q.ldR;
+            const int d = (int)(row % Dm), g = (int)(row / Dm);
+            st1(static_cast<IO *>(q.dtwio) + j, r < R ? p.w[((long long)src_group(g, 1) * Dm + d) * R + r] : 0.0f);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ss2d_block_params_fwd(int dtype, const float *A_logs, const float *Ds, const float *dt_bias, const float *dt_w,
+                                     const float *x_w, float *A, float *D, float *bias, float *w, void *xw, void *xwT, void *dtwT,
+                                     void *dtw_io, int Dm, int N, int R, int ldD, int ldC, int ldR, void *stream) {
+    if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("block_params_fwd: unknown dtype %d", dtype); return -1; }
+    if (!A_logs || !Ds || !dt_bias || !dt_w || !x_w || !A || !D || !bias || !w || !xw || !xwT || !dtwT) {
+        ss2d_set_error("block_params_fwd: null pointer"); return -2; }
+    if (Dm <= 0 || N <= 0 || R <= 0) { ss2d_set_error("block_params_fwd: non-positive size"); return -3; }
+    const int Cx = R + 2 * N;
+    if (ldD < Dm || ldC < 2 * Cx || (dtw_io && ldR < R)) { ss2d_set_error("block_params_fwd: leading dimension smaller than the row"); return -4; }
+    BlockParamsArgs q{};
+    q.sp.a = A_logs; q.sp.d = Ds; q.sp.b = dt_bias; q.sp.w = dt_w; q.sp.oa = A; q.sp.od = D; q.sp.ob = bias; q.sp.ow = w;
+    q.sp.K = 4; q.sp.Dm = Dm; q.sp.N = N; q.sp.R = R; q.sp.swap = 1;
+    q.xw_src = x_w; q.xw = xw; q.xwT = xwT; q.dtwT = dtwT; q.dtwio = dtw_io; q.Cx = Cx; q.ldD = ldD; q.ldC = ldC; q.ldR = ldR;
+    const long long total = (long long)4 * Dm * (N + 2 + R) + (long long)4 * Cx * ldD + (long long)2 * Dm * ldC + (long long)4 * R * ldD +
+                            (dtw_io ? (long long)4 * Dm * ldR : 0);
+    long long nwg = (total + 255) / 256;
+    if (nwg > 2048) nwg = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == SS2D_DTYPE_BF16) ss2d_launch((block_params_kernel<bf16, false>), dim3((unsigned)nwg), dim3(256), 0, s, q);
+    else ss2d_launch((block_params_kernel<float, false>), dim3((unsigned)nwg), dim3(256), 0, s, q);
+    const int rc = ss2d_take_launch_rc();
+    if (rc) ss2d_set_error("block_params_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
+extern "C" int ss2d_block_params_bwd(const float *A, const float *dA, const float *dD, const float *dbias, const float *dw,
+                                     const float *d_xw, float *dA_logs, float *dDs, float *ddt_bias, float *ddt_w, float *dx_w,
+                                     int Dm, int N, int R, void *stream) {
+    if (!A || !dA_logs || !dDs || !ddt_bias || !ddt_w || !dx_w) { ss2d_set_error("block_params_bwd: null pointer"); return -2; }
+    if (Dm <= 0 || N <= 0 || R <= 0) { ss2d_set_error("block_params_bwd: non-positive size"); return -3; }
+    BlockParamsArgs q{};
+    q.sp.A = A; q.sp.a = dA; q.sp.d = dD; q.sp.b = dbias; q.sp.w = dw; q.sp.oa = dA_logs; q.sp.od = dDs; q.sp.ob = ddt_bias; q.sp.ow = ddt_w;
+    q.sp.K = 4; q.sp.Dm = Dm; q.sp.N = N; q.sp.R = R; q.sp.swap = 1;
+    q.xw_src = d_xw; q.dxw = dx_w; q.Cx = R + 2 * N;
+    const long long total = (long long)4 * Dm * (N + 2 + R) + (long long)4 * q.Cx * Dm;
+    long long nwg = (total + 255) / 256;
+    if (nwg > 2048) nwg = 2048;
+    ss2d_launch((block_params_kernel<float, true>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, q);
+    const int rc = ss2d_take_launch_rc();
+    if (rc) ss2d_set_error("block_params_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+    return rc;
+}
+
 // ---- gradient of the x_proj output, assembled in one pass (mamba_sys.py:417, the autograd of `torch.split`):
 //     out[blk][c][l] = c < R ? d_dts[blk][c][l] : c < R+N ? dB[blk][c-R][l] : dC[blk][c-R-N][l]
 // d_dts in the activations' storage type, dB / dC the scan backward's fp32 accumulators: the two fp32 -> bf16 cast

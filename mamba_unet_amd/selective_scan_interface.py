@@ -252,7 +252,7 @@ class ScanCoreFn(torch.autograd.Function):
     FUSE_DELTA = not _os.environ.get("SS2D_NO_FUSE_DELTA")
 
     @staticmethod
-    def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None):
+    def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None, dtwT=None, dtw_io=None):
         ctx.holder = holder
         if not x_dbl.is_cuda:
             raise RuntimeError("scan_core_fn: GPU tensors required (no CPU path in mamba_unet_amd)")
@@ -287,7 +287,7 @@ class ScanCoreFn(torch.autograd.Function):
                 rc = lib.ss2d_dt_proj_fwd(code, _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(delta), batch, 4, Dch, R, L, Cx * L, _stream())
                 _lib.check(rc, "ss2d_dt_proj_fwd")
             else:   # other ranks (24 / 48 at stages 2 / 3): bf16 MFMA kernel over the dts rows in place, else the library GEMM
-                delta = chan_gemm(w32, xd[:, :, :R])
+                delta = chan_gemm(dtw_io, xd[:, :, :R], padded=True) if (dtw_io is not None and dtw_io.dtype == io) else chan_gemm(w32, xd[:, :, :R])
                 if delta is None:
                     with torch.autocast("cuda", enabled=False):
                         delta = torch.matmul(w32.to(io).unsqueeze(0), xd[:, :, :R])
@@ -304,14 +304,16 @@ class ScanCoreFn(torch.autograd.Function):
             rc = lib.ss2d_dirs_gather_ld(code, 1, _lib.ptr(out), _lib.ptr(y), batch, Dch, H, W, 1, L, _stream())
             _lib.check(rc, "ss2d_dirs_gather_ld")
         ctx.fused_delta = fused_delta
-        ctx.save_for_backward(u_, delta, A_, xd, w32, D_, bias_, ckpt)
+        if dtwT is not None and dtwT.dtype != io:
+            dtwT = None
+        ctx.save_for_backward(u_, delta, A_, xd, w32, D_, bias_, ckpt, dtwT)
         ctx.meta = (code, H, W, R, u2.dtype, x_dbl.dtype, dt_w.dtype, A.dtype, None if D is None else D.dtype,
                     None if delta_bias is None else delta_bias.dtype, None if x is None else x.dtype)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        u, delta, A, xd, w32, D, bias, ckpt = ctx.saved_tensors
+        u, delta, A, xd, w32, D, bias, ckpt, dtwT = ctx.saved_tensors
         code, H, W, R, u_dt, xdbl_dt, w_dt, A_dt, D_dt, b_dt, x_dt = ctx.meta
         batch, L = xd.shape[0], xd.shape[3]
         dim = A.shape[0]
@@ -365,7 +367,7 @@ class ScanCoreFn(torch.autograd.Function):
                 dd4 = ddelta.view(batch, 4, Dch, L)
                 # d_dts (b, 4, R, l) = dt_w^T . ddelta.  bf16: the own channel-major MFMA kernel; the library's batched GEMM first
                 # materialises the weight once per batch entry (a (b, 4, R, d) copy: 5-26 us per call on top of the product)
-                d_dts = chan_gemm(w32.transpose(1, 2), dd4)
+                d_dts = chan_gemm(dtwT, dd4, padded=True) if dtwT is not None else chan_gemm(w32.transpose(1, 2), dd4)
                 if d_dts is None:
                     d_dts = torch.matmul(w32.to(io).transpose(1, 2).unsqueeze(0), dd4).contiguous()
                 # (4, d, R): own MFMA kernel (bf16 25 / 19 / 13 us at stages 0-2 against the library's 61 / 42 / 28, fp32 -- as
@@ -378,13 +380,14 @@ class ScanCoreFn(torch.autograd.Function):
             _lib.check(rc, "ss2d_xdbl_grad_pack")
         cast = lambda t, d: None if t is None else t.to(d)  # noqa: E731
         return (cast(du2, u_dt), cast(d_xdbl, xdbl_dt), cast(d_w, w_dt), cast(dA, A_dt), cast(dD, D_dt), cast(dbias, b_dt),
-                None, None, cast(dx, x_dt), None)
+                None, None, cast(dx, x_dt), None, None, None)
 
 
-def scan_core_fn(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None):
+def scan_core_fn(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None, dtwT=None, dtw_io=None):
     """u2 (b, 2*d, l): row-major and column-major copies of x; x_dbl (b, 4, R+2N, l): the x_proj output with rows
     [dts | B | C] per scan group; dt_w (4, d, R); A (4*d, n), D, delta_bias (4*d) -- all in scan-group order
     (row-major, row-major reversed, column-major, column-major reversed).  delta = dt_w @ dts, softplus(delta + bias)
     as in SS2D.  l may exceed H*W: rows padded by the caller, u2 zero in the pad (SS2D._scan_core_dirs).  Returns y
-    (b, H, W, d) = CrossMerge of the four scans."""
-    return ScanCoreFn.apply(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x, holder)
+    (b, H, W, d) = CrossMerge of the four scans.  dtwT (4, R, d) / dtw_io (4, d, R): optional prepared copies of dt_w in the
+    activations' dtype with 16-byte padded rows (ss2d_ops.block_params), used in place by the dt_proj GEMMs."""
+    return ScanCoreFn.apply(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x, holder, dtwT, dtw_io)

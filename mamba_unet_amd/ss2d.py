@@ -25,8 +25,8 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import scan_core_fn, scan_merge_fn, selective_scan_fn
-from .ss2d_ops import (GradHalves, GradSlots, split_halves, apply_linear, apply_norm, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu, outnorm_gate,
-                       scan_params, x_proj)
+from .ss2d_ops import (GradHalves, GradSlots, split_halves, apply_linear, apply_norm, block_params, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu,
+                       outnorm_gate, scan_params, x_proj)
 
 
 class DropPath(nn.Module):
@@ -152,6 +152,14 @@ class SS2D(nn.Module):
             # parameter gradient sees it, and the gathers read the H*W real positions only.
             L = (L + 7) // 8 * 8
         xs2 = dirs_scatter2(x, slots, L)                                                        # (B, 2, D, L)
+        if core and x.is_cuda and self.x_proj_weight.dtype == torch.float32 and not os.environ.get("SS2D_NO_BLOCK_PARAMS"):
+            # every parameter-derived operand of the call from one launch (forward) / into one launch (backward): the
+            # stacked x_proj weight [orientation][rev*Cx + c], its transpose, dt_w and its transpose in the activations'
+            # dtype, A = -exp(A_logs), D, bias regrouped
+            A, Dv, bias, dt_w, xw, xwT, dtwT, dtw_io, pg = block_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight,
+                                                                         self.x_proj_weight, x.dtype, want_dtw_io=R not in (6, 12))
+            x_dbl = x_proj(xw, xs2, xwT, pg).view(B, 4, Cx, L)                          # group = 2*orientation + rev
+            return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x, holder=slots, dtwT=dtwT, dtw_io=dtw_io)
         w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
         x_dbl = x_proj(w_cat, xs2).view(B, 4, Cx, L)                                    # group = 2*orientation + rev
         A, Dv, bias, dt_w = scan_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight, regroup=True)

@@ -233,11 +233,12 @@ def chan_wgrad(P: torch.Tensor, Q: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def chan_gemm(W: torch.Tensor, X: torch.Tensor):
+def chan_gemm(W: torch.Tensor, X: torch.Tensor, padded: bool = False):
     """Y (B, G, M, L) = W (G, M, K) @ X (B, G, K, L) for a channel-major X (bf16 or fp32) whose rows are L apart (row ranges
     of wider blocks are fine): x_proj, dt_proj and their input gradients (mamba_sys.py:407, :420) on the MFMA kernels of
     csrc/ss2d_cmgemm.hip (fp32: three-way bf16 split, fp32 results).  Y has X's dtype.  None when dtype or layout do not
-    qualify (the caller then uses the BLAS library)."""
+    qualify (the caller then uses the BLAS library).  `padded`: W is a (G, M, K) view of a buffer in X's dtype whose rows
+    are already padded with zeros to a multiple of 16 bytes (block_params): used in place, no cast / pad launches."""
     _need_gpu(X, "chan_gemm")
     B, G, K, L = X.shape
     M = W.shape[1]
@@ -247,12 +248,18 @@ def chan_gemm(W: torch.Tensor, X: torch.Tensor):
     if not (X.stride(3) == 1 and X.stride(2) == L and X.stride(0) % 4 == 0 and X.stride(1) % 4 == 0) or X.data_ptr() % (16 if f32 else 8):
         return None
     q = 4 if f32 else 8                                               # W rows are padded with zeros to 16 bytes
-    ldw = (K + q - 1) // q * q
-    Wp = W.to(X.dtype)
-    Wp = torch.nn.functional.pad(Wp, (0, ldw - K)) if ldw != K else Wp.contiguous()
+    if padded:
+        if W.dtype != X.dtype or W.stride(2) != 1 or W.stride(1) % q or W.stride(1) < K or W.stride(0) % q or W.data_ptr() % 16:
+            raise ValueError("chan_gemm: `padded` weight is not a view of a 16-byte padded buffer in the activations' dtype")
+        Wp, ldw, swg = W, W.stride(1), W.stride(0)
+    else:
+        ldw = (K + q - 1) // q * q
+        Wp = W.to(X.dtype)
+        Wp = torch.nn.functional.pad(Wp, (0, ldw - K)) if ldw != K else Wp.contiguous()
+        swg = M * ldw
     Y = torch.empty((B, G, M, L), device=X.device, dtype=X.dtype)
     with _lib.on_device(X.device):
-        rc = _lib.load().ss2d_chan_gemm(_F32 if f32 else _BF16, _lib.ptr(Wp), _lib.ptr(X), _lib.ptr(Y), B, G, M, K, ldw, L, M * ldw,
+        rc = _lib.load().ss2d_chan_gemm(_F32 if f32 else _BF16, _lib.ptr(Wp), _lib.ptr(X), _lib.ptr(Y), B, G, M, K, ldw, L, swg,
                                         X.stride(0), X.stride(1), G * M * L, M * L, _stream())
     _lib.check(rc, "ss2d_chan_gemm")
     return Y
@@ -262,16 +269,22 @@ class _XProj(torch.autograd.Function):
     """x_dbl[b, o] = W[o] @ xs[b, o] (mamba_sys.py:407 with the two directions of an orientation stacked in W).  bf16:
     forward and dX on the MFMA kernel of csrc/ss2d_cmgemm.hip (26 / 14 / 19 us and 27 / 20 / 12 us at stages 0-2 against
     the library's 56 / 23 / 24 and 49 / 41 / 30), dW on csrc/ss2d_cmwgrad.hip where it is the faster one (long rows);
-    fp32 and odd layouts: the library's batched GEMM."""
+    fp32 and odd layouts: the library's batched GEMM.
+    With `wT` and `holder` (block_params): w / wT are the prepared operands (activations' dtype, padded rows) and are used
+    in place; the fp32 weight gradient is left in holder.d_xw for block_params' backward, which regroups it into
+    x_proj_weight's layout -- w itself gets no gradient from this node."""
 
     @staticmethod
-    def forward(ctx, w, xs):
+    def forward(ctx, w, xs, wT=None, holder=None):
         if torch.is_autocast_enabled():
             xs = xs.to(torch.get_autocast_dtype("cuda"))
-        w2 = w.to(xs.dtype)
-        ctx.save_for_backward(w2, xs)
+        ctx.holder = holder
+        prepared = wT is not None and w.dtype == xs.dtype
+        ctx.prepared = prepared
+        w2 = w if prepared else w.to(xs.dtype)
+        ctx.save_for_backward(w2, xs, wT if prepared else None)
         ctx.w_dtype = w.dtype
-        y = chan_gemm(w2, xs)
+        y = chan_gemm(w2, xs, padded=prepared)
         if y is None:
             with torch.autocast("cuda", enabled=False):
                 y = torch.matmul(w2.unsqueeze(0), xs)
@@ -279,26 +292,29 @@ class _XProj(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        w2, xs = ctx.saved_tensors
+        w2, xs, wT = ctx.saved_tensors
         g = g.to(xs.dtype)
         g = g if g.is_contiguous() else g.contiguous()
         dxs = dw = None
+        want_dw = ctx.needs_input_grad[0] or (ctx.holder is not None and ctx.holder.want_xw)
         with torch.autocast("cuda", enabled=False):
             if ctx.needs_input_grad[1]:
-                dxs = chan_gemm(w2.transpose(1, 2), g)
+                dxs = chan_gemm(wT, g, padded=True) if ctx.prepared else chan_gemm(w2.transpose(1, 2), g)
                 if dxs is None:
                     dxs = torch.matmul(w2.transpose(1, 2).unsqueeze(0), g)
-            if ctx.needs_input_grad[0]:
+            if want_dw:
                 dw = chan_wgrad(g, xs) if g.dtype == torch.bfloat16 and g.shape[-1] >= 512 else None
                 if dw is None:
                     dw = torch.matmul(g, xs.transpose(2, 3)).sum(0, dtype=torch.float32)
-                dw = dw.to(ctx.w_dtype)
-        return dw, dxs
+        if ctx.holder is not None:
+            ctx.holder.d_xw = dw          # fp32 (2, 2Cx, D): picked up by _BlockParams.backward
+            return None, dxs, None, None
+        return (None if dw is None else dw.to(ctx.w_dtype)), dxs, None, None
 
 
-def x_proj(w: torch.Tensor, xs: torch.Tensor) -> torch.Tensor:
+def x_proj(w: torch.Tensor, xs: torch.Tensor, wT=None, holder=None) -> torch.Tensor:
     """w (G, C, D), xs (B, G, D, L) -> (B, G, C, L): the x_proj of mamba_sys.py:407 for channel-major activations."""
-    return _XProj.apply(w, xs)
+    return _XProj.apply(w, xs, wT, holder)
 
 
 def colsum(g: torch.Tensor) -> torch.Tensor:
@@ -890,6 +906,83 @@ def scan_params(A_logs: torch.Tensor, Ds: torch.Tensor, dt_projs_bias: torch.Ten
     (A = -exp(A_logs) (K*D, N), D (K*D), delta_bias (K*D), dt weight (K, D, R)), fp32; with `regroup` in the
     scan-group order (row-major, row-major reversed, column-major, column-major reversed) of `scan_merge_fn`."""
     return _ScanParams.apply(A_logs, Ds, dt_projs_bias, dt_projs_weight, regroup)
+
+
+class BlockGrads:
+    """The weight gradient of the stacked x_proj on its way from _XProj.backward to _BlockParams.backward (fp32; a plain
+    attribute, like GradSlots: autograd would cast a gradient returned for the bf16 operand to bf16 first)."""
+    __slots__ = ("d_xw", "want_xw")
+
+    def __init__(self, want_xw: bool):
+        self.d_xw, self.want_xw = None, want_xw
+
+
+class _BlockParams(torch.autograd.Function):
+    """Every parameter-derived operand of one fused-direction SS2D call in one launch each way (csrc/ss2d_scanparams.hip,
+    ss2d_block_params_*): scan_params(regroup=True) plus the stacked x_proj weight, its transpose, the dt_proj weight
+    transposed and (ranks other than 6 / 12) the dt_proj weight, in the activations' dtype with 16-byte padded rows --
+    the operands chan_gemm takes in place.  As torch ops: a regrouping copy, a cast, a transposing copy and a pad per
+    operand and block (mamba_sys.py:407, :420, :428-431 are views / einsum operands there)."""
+
+    @staticmethod
+    def forward(ctx, A_logs, Ds, dt_bias, dt_w, x_w, io, holder, want_dtw_io):
+        _need_gpu(A_logs, "block_params")
+        K, Dm, R = dt_w.shape
+        N, Cx = A_logs.shape[1], x_w.shape[1]
+        if K != 4 or A_logs.shape[0] != K * Dm or Ds.numel() != K * Dm or dt_bias.numel() != K * Dm or tuple(x_w.shape) != (4, Cx, Dm) or Cx != R + 2 * N:
+            raise ValueError("block_params: inconsistent parameter shapes")
+        src = [t.detach().float().contiguous() for t in (A_logs, Ds, dt_bias, dt_w, x_w)]
+        dev = A_logs.device
+        q = 4 if io == torch.float32 else 8
+        up = lambda v: (v + q - 1) // q * q  # noqa: E731
+        ldD, ldC, ldR = up(Dm), up(2 * Cx), up(R)
+        A = torch.empty((K * Dm, N), device=dev, dtype=torch.float32)
+        D = torch.empty((K * Dm,), device=dev, dtype=torch.float32)
+        bias = torch.empty((K * Dm,), device=dev, dtype=torch.float32)
+        w = torch.empty((K, Dm, R), device=dev, dtype=torch.float32)
+        xw = torch.empty((2, 2 * Cx, ldD), device=dev, dtype=io)
+        xwT = torch.empty((2, Dm, ldC), device=dev, dtype=io)
+        dtwT = torch.empty((4, R, ldD), device=dev, dtype=io)
+        dtw_io = torch.empty((4, Dm, ldR), device=dev, dtype=io) if want_dtw_io else None
+        with _lib.on_device(dev):
+            rc = _lib.load().ss2d_block_params_fwd(_F32 if io == torch.float32 else _BF16, *[_lib.ptr(t) for t in src], _lib.ptr(A),
+                                                   _lib.ptr(D), _lib.ptr(bias), _lib.ptr(w), _lib.ptr(xw), _lib.ptr(xwT), _lib.ptr(dtwT),
+                                                   _lib.ptr(dtw_io), Dm, N, R, ldD, ldC, ldR, _stream())
+        _lib.check(rc, "ss2d_block_params_fwd")
+        ctx.save_for_backward(A)
+        ctx.holder = holder
+        ctx.meta = (Dm, N, R, Cx, A_logs.dtype, Ds.dtype, dt_bias.dtype, dt_w.dtype, x_w.dtype, tuple(dt_bias.shape))
+        outs = (xw[:, :, :Dm], xwT[:, :, :2 * Cx], dtwT[:, :, :Dm]) + ((dtw_io[:, :, :R],) if want_dtw_io else ())
+        ctx.mark_non_differentiable(*outs)
+        return (A, D, bias, w) + outs + ((None,) if not want_dtw_io else ())
+
+    @staticmethod
+    def backward(ctx, dA, dD, dbias, dw, *unused):
+        (A,) = ctx.saved_tensors
+        Dm, N, R, Cx, *dts, bias_shape = ctx.meta
+        d_xw = ctx.holder.d_xw if ctx.holder is not None else None
+        if ctx.holder is not None:
+            ctx.holder.d_xw = None
+        g = [None if t is None else t.float().contiguous() for t in (dA, dD, dbias, dw, d_xw)]
+        dev = A.device
+        dA_logs = torch.empty((4 * Dm, N), device=dev, dtype=torch.float32)
+        dDs = torch.empty((4 * Dm,), device=dev, dtype=torch.float32)
+        ddt_bias = torch.empty(bias_shape, device=dev, dtype=torch.float32)
+        ddt_w = torch.empty((4, Dm, R), device=dev, dtype=torch.float32)
+        dx_w = torch.empty((4, Cx, Dm), device=dev, dtype=torch.float32)
+        with _lib.on_device(dev):
+            rc = _lib.load().ss2d_block_params_bwd(_lib.ptr(A), *[_lib.ptr(t) for t in g], _lib.ptr(dA_logs), _lib.ptr(dDs),
+                                                   _lib.ptr(ddt_bias), _lib.ptr(ddt_w), _lib.ptr(dx_w), Dm, N, R, _stream())
+        _lib.check(rc, "ss2d_block_params_bwd")
+        return dA_logs.to(dts[0]), dDs.to(dts[1]), ddt_bias.to(dts[2]), ddt_w.to(dts[3]), dx_w.to(dts[4]), None, None, None
+
+
+def block_params(A_logs, Ds, dt_projs_bias, dt_projs_weight, x_proj_weight, io, want_dtw_io: bool = False):
+    """-> (A, D, delta_bias, dt_w) fp32 in scan-group order (as scan_params(regroup=True)), xw (2, 2Cx, D), xwT (2, D, 2Cx),
+    dtwT (4, R, D), dtw_io (4, D, R) or None: views of 16-byte padded buffers in dtype `io` (chan_gemm(..., padded=True)),
+    and the BlockGrads holder that x_proj(..., holder=) fills in its backward."""
+    holder = BlockGrads(x_proj_weight.requires_grad)
+    return _BlockParams.apply(A_logs, Ds, dt_projs_bias, dt_projs_weight, x_proj_weight, io, holder, want_dtw_io) + (holder,)
 
 
 class _LNHead(torch.autograd.Function):

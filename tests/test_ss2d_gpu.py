@@ -381,6 +381,51 @@ def test_scan_params_kernel(Dm, N, R, regroup):
         assert got.grad.shape == want.grad.shape and rel_l2(got.grad.cpu(), want.grad) < 1e-6
 
 
+@pytest.mark.parametrize("Dm,N,R,io", [(192, 16, 6, torch.bfloat16), (192, 16, 6, torch.float32), (1536, 16, 48, torch.bfloat16),
+                                       (20, 16, 3, torch.bfloat16), (20, 16, 3, torch.float32)])
+def test_block_params_kernel(Dm, N, R, io):
+    """Every parameter-derived operand of a fused-direction SS2D call from one launch (mamba_sys.py:407, :420, :428-431):
+    scan_params(regroup=True) plus the stacked x_proj weight, its transpose, dt_w transposed and dt_w, rounded to the
+    activations' dtype in zero-padded rows; the backward regroups the stacked weight gradient into x_proj_weight's layout.
+    Permutations and casts: bit-exact against the torch composition; A = -exp: fp32 tolerance."""
+    from mamba_unet_amd.ss2d_ops import block_params
+    K, Cx = 4, R + 2 * N
+    gen = torch.Generator().manual_seed(Dm + R)
+    A_logs = torch.log(torch.rand(K * Dm, N, generator=gen) * 15 + 1)
+    Ds, bias, w = torch.randn(K * Dm, generator=gen), torch.randn(K, Dm, generator=gen), torch.randn(K, Dm, R, generator=gen)
+    xw = torch.randn(K, Cx, Dm, generator=gen)
+    order = [0, 2, 1, 3]
+    dev_in = [t.cuda().requires_grad_(True) for t in (A_logs, Ds, bias, w, xw)]
+    A, D, b, dtw, sxw, sxwT, dtwT, dtw_io, holder = block_params(*dev_in, io, want_dtw_io=True)
+    assert rel_l2(A.detach().cpu(), (-torch.exp(A_logs.double())).view(K, Dm, N)[order].reshape(K * Dm, N)) < 1e-6
+    assert torch.equal(D.detach().cpu(), Ds.view(K, Dm)[order].reshape(-1)) and torch.equal(b.detach().cpu(), bias[order].reshape(-1))
+    assert torch.equal(dtw.detach().cpu(), w[order])
+    w_cat = xw.view(2, 2, Cx, Dm).transpose(0, 1).reshape(2, 2 * Cx, Dm)          # [orientation][rev*Cx + c]
+    assert sxw.dtype == io and torch.equal(sxw.cpu(), w_cat.to(io))
+    assert torch.equal(sxwT.cpu(), w_cat.transpose(1, 2).to(io))
+    assert torch.equal(dtwT.cpu(), w[order].transpose(1, 2).to(io)) and torch.equal(dtw_io.cpu(), w[order].to(io))
+    q = 4 if io == torch.float32 else 8
+    for t, k in ((sxw, Dm), (sxwT, 2 * Cx), (dtwT, Dm), (dtw_io, R)):              # rows padded to 16 bytes with zeros
+        ld = t.stride(1)
+        assert ld % q == 0 and ld >= k and t.data_ptr() % 16 == 0
+        full = torch.as_strided(t, (t.shape[0], t.shape[1], ld), (t.stride(0), ld, 1))
+        assert not full[:, :, k:].any()
+    assert not any(t.requires_grad for t in (sxw, sxwT, dtwT, dtw_io))
+    grads = [torch.randn(K * Dm, N, generator=gen), torch.randn(K * Dm, generator=gen), torch.randn(K * Dm, generator=gen),
+             torch.randn(K, Dm, R, generator=gen)]
+    d_xw = torch.randn(2, 2 * Cx, Dm, generator=gen)
+    holder.d_xw = d_xw.cuda()                                                       # what x_proj's backward leaves there
+    torch.autograd.backward([A, D, b, dtw], [g.cuda() for g in grads])
+    assert holder.d_xw is None
+    inv = [0, 2, 1, 3]
+    assert rel_l2(dev_in[0].grad.cpu(), (grads[0].double() * (-torch.exp(A_logs.double())).view(K, Dm, N)[order].reshape(K * Dm, N))
+                  .view(K, Dm, N)[inv].reshape(K * Dm, N)) < 1e-6
+    assert torch.equal(dev_in[1].grad.cpu(), grads[1].view(K, Dm)[inv].reshape(-1))
+    assert torch.equal(dev_in[2].grad.cpu(), grads[2].view(K, Dm)[inv])
+    assert torch.equal(dev_in[3].grad.cpu(), grads[3][inv])
+    assert torch.equal(dev_in[4].grad.cpu(), d_xw.view(2, 2, Cx, Dm).transpose(0, 1).reshape(K, Cx, Dm))
+
+
 @pytest.mark.parametrize("B,H,W,c,p,dtype", [(2, 5, 7, 24, 2, torch.float32), (1, 14, 14, 96, 4, torch.float32),
                                              (2, 7, 7, 384, 2, torch.float32), (2, 14, 14, 96, 4, torch.bfloat16)])
 def test_layer_norm_over_pixel_unshuffle(B, H, W, c, p, dtype):
