@@ -265,6 +265,12 @@ int ss2d_layernorm_fwd(int in_dtype, int out_dtype, const void *x, const float *
 int ss2d_layernorm_bwd(int in_dtype, int out_dtype, const void *dout, const void *x, const float *gamma,
                        const float *mean, const float *rstd, void *dx, float *dgamma, float *dbeta, long long rows,
                        int D, void *stream);
+/* The same with a second gradient of x added to dx as it is written: `add` (rows x D, x's dtype) is the gradient that
+ * arrives over the residual connection around the norm (mamba_sys.py:583-585: the block input feeds ln_1 and the sum);
+ * autograd would add the two in a pass of its own.  dx may alias neither x nor add. */
+int ss2d_layernorm_bwd_add(int in_dtype, int out_dtype, const void *dout, const void *x, const float *gamma,
+                           const float *mean, const float *rstd, const void *add, void *dx, float *dgamma, float *dbeta,
+                           long long rows, int D, void *stream);
 
 /* The same LayerNorm over the rows of a ps x ps pixel un-shuffle of x: x (batch, H, W, ps*ps*D) as the expand Linear
  * of PatchExpand / FinalPatchExpand_X4 leaves it (mamba_sys.py:233-265), out / dout (batch, H*ps, W*ps, D) =

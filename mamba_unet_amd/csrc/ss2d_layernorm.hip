@@ -17,6 +17,7 @@ struct LNParams {
     const void *x, *dout;
     const float *gamma, *beta, *mean_in, *rstd_in;
     void *out, *dx;
+    const void *add;    // backward (plain rows): a second gradient of x, added to dx as it is written (the residual path)
     float *mean, *rstd, *dgamma, *dbeta;
     long long rows;
     int D;
@@ -111,7 +112,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const LNParams p) {
     }
 }
 
-template <int K, int NWV, int LW, typename TI, typename TO>
+// ADD: dx = LayerNorm backward + p.add (the gradient arriving over the residual connection around the norm: the block's
+// input feeds ln_1 and the residual sum, mamba_sys.py:583-585, and autograd would add the two gradients in a pass of its own)
+template <int K, int NWV, int LW, typename TI, typename TO, bool ADD = false>
 __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
     __shared__ __attribute__((aligned(16))) float red[NWV * 2 * K * 256];
     constexpr int RPW = 64 / LW;
@@ -135,10 +138,11 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
     const float invD = 1.0f / (float)D;
     // the next row of the wave (or half-wave) is requested before this one is worked on -- see normgate_bwd_kernel; loads are
     // never under a branch: chunks past D and rows past the end read a clamped address and are not used
-    f4 gv[K], xv[K];
+    f4 gv[K], xv[K], av[ADD ? K : 1];
     float mu = 0.0f, rstd = 0.0f;
     long long xoff = 0;
-    auto fetch = [&](long long r_, f4 (&g_)[K], f4 (&x_)[K], float &mu_, float &rs_, long long &xo_) {
+    const TI *__restrict__ AD = static_cast<const TI *>(p.add);
+    auto fetch = [&](long long r_, f4 (&g_)[K], f4 (&x_)[K], f4 (&a_)[ADD ? K : 1], float &mu_, float &rs_, long long &xo_) {
         const long long rc = r_ < p.rows ? r_ : p.rows - 1;
         mu_ = p.mean_in[rc];
         rs_ = p.rstd_in[rc];
@@ -148,14 +152,15 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
             const int c = lane + LW * k, cc = c < nchunk ? c : nchunk - 1;
             g_[k] = ld4(G + rc * D + 4 * cc);
             x_[k] = ld4(X + xo_ + co[k]);      // co[k] is already clamped to chunk 0 for c >= nchunk
+            if (ADD) a_[k] = ld4(AD + xo_ + co[k]);
         }
     };
-    if (wave0 < p.rows) fetch(wave0, gv, xv, mu, rstd, xoff);
+    if (wave0 < p.rows) fetch(wave0, gv, xv, av, mu, rstd, xoff);
     for (long long r = wave0; r < p.rows; r += nwaves) {
-        f4 gn[K], xn[K];
+        f4 gn[K], xn[K], an[ADD ? K : 1];
         float mun, rsn;
         long long xon;
-        fetch(r + nwaves, gn, xn, mun, rsn, xon);
+        fetch(r + nwaves, gn, xn, an, mun, rsn, xon);
         f4 nh[K], dn[K];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -177,10 +182,10 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + LW * k;
-            if (c < nchunk) st4(DX + xoff + co[k], (dn[k] - m1 - nh[k] * m2) * rstd);
+            if (c < nchunk) st4(DX + xoff + co[k], ADD ? (dn[k] - m1 - nh[k] * m2) * rstd + av[k] : (dn[k] - m1 - nh[k] * m2) * rstd);
         }
 #pragma unroll
-        for (int k = 0; k < K; ++k) { gv[k] = gn[k]; xv[k] = xn[k]; }
+        for (int k = 0; k < K; ++k) { gv[k] = gn[k]; xv[k] = xn[k]; if (ADD) av[k] = an[k]; }
         mu = mun;
         rstd = rsn;
         xoff = xon;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(NWV * 64) void ln_bwd_kernel(const LNParams p) {
     wg_colsum2<K, NWV, LW>(red, ag, ab, D, p.dgamma, p.dbeta);
 }
 
-template <typename TI, typename TO>
+template <typename TI, typename TO, bool ADD = false>
 void launch_ln(bool bwd, const LNParams &p, hipStream_t s) {
     const int nchunk = p.D / 4;
     const bool half = nchunk <= 32;              // two rows per wave
@@ -213,14 +218,14 @@ void launch_ln(bool bwd, const LNParams &p, hipStream_t s) {
     long long nwg = (p.rows + nwv * rpw - 1) / (nwv * rpw);
     if (nwg > 256) nwg = 256;
     const dim3 grid((unsigned)nwg), block(nwv * 64);
-    if (half) { ss2d_launch((ln_bwd_kernel<1, 16, 32, TI, TO>), grid, block, 0, s, p); return; }
+    if (half) { ss2d_launch((ln_bwd_kernel<1, 16, 32, TI, TO, ADD>), grid, block, 0, s, p); return; }
     switch (K) {
-        case 1: ss2d_launch((ln_bwd_kernel<1, 16, 64, TI, TO>), grid, block, 0, s, p); break;
-        case 2: ss2d_launch((ln_bwd_kernel<2, 16, 64, TI, TO>), grid, block, 0, s, p); break;
-        case 3: ss2d_launch((ln_bwd_kernel<3, 4, 64, TI, TO>), grid, block, 0, s, p); break;
-        case 4: ss2d_launch((ln_bwd_kernel<4, 4, 64, TI, TO>), grid, block, 0, s, p); break;
-        case 5: ss2d_launch((ln_bwd_kernel<5, 4, 64, TI, TO>), grid, block, 0, s, p); break;
-        default: ss2d_launch((ln_bwd_kernel<6, 4, 64, TI, TO>), grid, block, 0, s, p); break;
+        case 1: ss2d_launch((ln_bwd_kernel<1, 16, 64, TI, TO, ADD>), grid, block, 0, s, p); break;
+        case 2: ss2d_launch((ln_bwd_kernel<2, 16, 64, TI, TO, ADD>), grid, block, 0, s, p); break;
+        case 3: ss2d_launch((ln_bwd_kernel<3, 4, 64, TI, TO, ADD>), grid, block, 0, s, p); break;
+        case 4: ss2d_launch((ln_bwd_kernel<4, 4, 64, TI, TO, ADD>), grid, block, 0, s, p); break;
+        case 5: ss2d_launch((ln_bwd_kernel<5, 4, 64, TI, TO, ADD>), grid, block, 0, s, p); break;
+        default: ss2d_launch((ln_bwd_kernel<6, 4, 64, TI, TO, ADD>), grid, block, 0, s, p); break;
     }
 }
 
@@ -231,7 +236,11 @@ int dispatch(bool bwd, int in_dtype, int out_dtype, const LNParams &p, void *str
     if (p.rows <= 0 || p.D <= 0) { ss2d_set_error("%s: non-positive size", name); return -3; }
     if (p.D % 4 || p.D > 256 * MAXK) { ss2d_set_error("%s: D %d must be a multiple of 4 and <= %d", name, p.D, 256 * MAXK); return -4; }
     hipStream_t s = (hipStream_t)stream;
-    if (in_dtype == SS2D_DTYPE_F32 && out_dtype == SS2D_DTYPE_F32) launch_ln<float, float>(bwd, p, s);
+    if (bwd && p.add) {
+        if (in_dtype == SS2D_DTYPE_F32 && out_dtype == SS2D_DTYPE_F32) launch_ln<float, float, true>(bwd, p, s);
+        else if (in_dtype == SS2D_DTYPE_F32) launch_ln<float, bf16, true>(bwd, p, s);
+        else launch_ln<bf16, bf16, true>(bwd, p, s);
+    } else if (in_dtype == SS2D_DTYPE_F32 && out_dtype == SS2D_DTYPE_F32) launch_ln<float, float>(bwd, p, s);
     else if (in_dtype == SS2D_DTYPE_F32) launch_ln<float, bf16>(bwd, p, s);
     else launch_ln<bf16, bf16>(bwd, p, s);
     const int rc = ss2d_take_launch_rc();
@@ -258,6 +267,16 @@ extern "C" int ss2d_layernorm_bwd(int in_dtype, int out_dtype, const void *dout,
     p.dout = dout; p.x = x; p.gamma = gamma; p.mean_in = mean; p.rstd_in = rstd; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
     p.rows = rows; p.D = D;
     return dispatch(true, in_dtype, out_dtype, p, stream, "layernorm_bwd");
+}
+
+extern "C" int ss2d_layernorm_bwd_add(int in_dtype, int out_dtype, const void *dout, const void *x, const float *gamma,
+                                      const float *mean, const float *rstd, const void *add, void *dx, float *dgamma,
+                                      float *dbeta, long long rows, int D, void *stream) {
+    if (!dout || !x || !gamma || !mean || !rstd || !add || !dx || !dgamma || !dbeta) { ss2d_set_error("layernorm_bwd_add: null pointer"); return -2; }
+    LNParams p{};
+    p.dout = dout; p.x = x; p.gamma = gamma; p.mean_in = mean; p.rstd_in = rstd; p.add = add; p.dx = dx; p.dgamma = dgamma; p.dbeta = dbeta;
+    p.rows = rows; p.D = D;
+    return dispatch(true, in_dtype, out_dtype, p, stream, "layernorm_bwd_add");
 }
 
 // ---- LayerNorm + segmentation head in one pass (the tail of VSSM.up_x4, mamba_sys.py:859-866: FinalPatchExpand_X4's

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import scan_core_fn, scan_merge_fn, selective_scan_fn
-from .ss2d_ops import (GradHalves, GradSlots, split_halves, apply_linear, apply_norm, block_params, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu,
+from .ss2d_ops import (GradHalves, GradSlots, split_halves, apply_linear, apply_norm, apply_norm_skip, block_params, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu,
                        outnorm_gate, scan_params, x_proj)
 
 
@@ -255,16 +255,27 @@ class VSSBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, input: torch.Tensor):
-        y = self.self_attention(apply_norm(self.ln_1, input))
+        ln, input = apply_norm_skip(self.ln_1, input)     # `input` again, with its residual gradient routed through ln_1's backward kernel
+        y = self.self_attention(ln)
         dp = self.drop_path
         if type(dp) is DropPath and dp.training and dp.drop_prob > 0.0:
             # residual + stochastic depth in one pass (same Bernoulli draw as DropPath.forward; y*(mask/keep) instead
             # of (y*mask)/keep): input + y * mask / keep
-            keep = 1.0 - dp.drop_prob
-            mask = y.new_empty((y.shape[0],) + (1,) * (y.dim() - 1)).bernoulli_(keep)
-            # the scale in the residual stream's precision (1 / keep rounded to bf16 first would bias the branch by up to 0.4 %)
-            return _ResidualScaled.apply(input, y, mask.to(input.dtype).div_(keep))
+            scale = self._dp_scale
+            if scale is not None and not self._dp_keep:
+                self._dp_scale = None                      # one forward only (kept for a checkpointed stage's recomputation)
+            if scale is None or scale.shape[0] != y.shape[0] or scale.device != y.device or scale.dtype != input.dtype:
+                keep = 1.0 - dp.drop_prob
+                mask = y.new_empty((y.shape[0],) + (1,) * (y.dim() - 1)).bernoulli_(keep)
+                # the scale in the residual stream's precision (1 / keep rounded to bf16 first would bias the branch by up to 0.4 %)
+                scale = mask.to(input.dtype).div_(keep)
+            return _ResidualScaled.apply(input, y, scale.view((y.shape[0],) + (1,) * (y.dim() - 1)))
         return input + dp(y)
+
+    # per-sample scale mask / keep of this forward, drawn for all blocks of the network at once (VSSM.forward: one Bernoulli
+    # launch per step instead of three small launches per block); None: the block draws its own
+    _dp_scale = None
+    _dp_keep = False
 
 
 def _burn_out_proj_rng(module: nn.Module):

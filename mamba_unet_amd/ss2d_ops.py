@@ -628,7 +628,7 @@ class _LayerNorm(torch.autograd.Function):
     with ps = -2 over the 2x2 neighbourhoods of x (B, H, W, C): out (B, H/2, W/2, 4C) = norm(x0 | x1 | x2 | x3)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, ps=0):
+    def forward(ctx, x, weight, bias, eps, ps=0, skip=False):
         _need_gpu(x, "layer_norm")
         io, code = _io(x)
         if ps < 0:
@@ -669,15 +669,27 @@ class _LayerNorm(torch.autograd.Function):
         _lib.check(rc, "ss2d_layernorm_fwd")
         ctx.save_for_backward(x2, g32, mean, rstd)
         ctx.meta = (code, ocode, odt, rows, D, x.shape, x.dtype, weight.dtype, bias.dtype, ps)
+        if skip:
+            # (out, x): x leaves as a second output, so that the gradient of everything else that consumes x -- the
+            # residual sum around the norm -- arrives HERE and is added inside the backward kernel (ss2d_layernorm_bwd_add)
+            # instead of by autograd's accumulation pass
+            ctx.set_materialize_grads(False)
+            return out.view(out_shape), x.view_as(x)
         return out.view(out_shape)
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dskip=None):
         x2, g32, mean, rstd = ctx.saved_tensors
         code, ocode, odt, rows, D, xshape, xdt, wdt, bdt, ps = ctx.meta
+        if dout is None:       # only the pass-through output was used
+            return (None if dskip is None else dskip.to(xdt)), None, None, None, None, None
         g = dout.reshape(rows, D).to(odt)
         g = g if g.is_contiguous() else g.contiguous()
         dx = torch.empty_like(x2)
+        add = None
+        if dskip is not None and ps == 0:
+            add = dskip.reshape(rows, D).to(x2.dtype)
+            add = add if add.is_contiguous() else add.contiguous()
         dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(g32.shape))
         lib = _lib.load()
         with _lib.on_device(g.device):
@@ -689,11 +701,17 @@ class _LayerNorm(torch.autograd.Function):
                 B, H, W, _ = xshape
                 rc = lib.ss2d_layernorm_unshuffle_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
                                                       _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), B, H, W, ps, D, _stream())
+            elif add is not None:
+                rc = lib.ss2d_layernorm_bwd_add(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean), _lib.ptr(rstd),
+                                                _lib.ptr(add), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), rows, D, _stream())
             else:
                 rc = lib.ss2d_layernorm_bwd(code, ocode, _lib.ptr(g), _lib.ptr(x2), _lib.ptr(g32), _lib.ptr(mean),
                                             _lib.ptr(rstd), _lib.ptr(dx), _lib.ptr(dg), _lib.ptr(db), rows, D, _stream())
         _lib.check(rc, "ss2d_layernorm_bwd")
-        return dx.view(xshape).to(xdt), dg.to(wdt), db.to(bdt), None, None
+        dx = dx.view(xshape).to(xdt)
+        if dskip is not None and add is None:      # gathered rows (ps != 0): not fused
+            dx = dx + dskip.to(xdt)
+        return dx, dg.to(wdt), db.to(bdt), None, None, None
 
 
 def layer_norm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
@@ -721,6 +739,19 @@ def apply_norm(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
             and module.bias is not None and x.is_cuda:
         return layer_norm(x, module.weight, module.bias, module.eps)
     return module(x)
+
+
+_NO_LN_SKIP = bool(__import__("os").environ.get("SS2D_NO_LN_SKIP"))     # A/B switch
+
+
+def apply_norm_skip(module: torch.nn.Module, x: torch.Tensor):
+    """(module(x), x') with x' == x: for `x + f(norm(x))` (VSSBlock, mamba_sys.py:583-585).  Using x' in the residual sum
+    routes its gradient through the norm's backward kernel, which adds it to dx in the same pass."""
+    if type(module) is torch.nn.LayerNorm and len(module.normalized_shape) == 1 and module.elementwise_affine \
+            and module.bias is not None and x.is_cuda and x.shape[-1] % 4 == 0 and x.shape[-1] <= 1536 and torch.is_grad_enabled() and x.requires_grad \
+            and not _NO_LN_SKIP:
+        return _LayerNorm.apply(x, module.weight, module.bias, module.eps, 0, True)
+    return apply_norm(module, x), x
 
 
 def pixel_unshuffle_cl(x: torch.Tensor, p: int) -> torch.Tensor:
@@ -951,6 +982,7 @@ class _BlockParams(torch.autograd.Function):
         _lib.check(rc, "ss2d_block_params_fwd")
         ctx.save_for_backward(A)
         ctx.holder = holder
+        ctx.set_materialize_grads(False)     # (the non-differentiable outputs would each get a zero-filled gradient tensor)
         ctx.meta = (Dm, N, R, Cx, A_logs.dtype, Ds.dtype, dt_bias.dtype, dt_w.dtype, x_w.dtype, tuple(dt_bias.shape))
         outs = (xw[:, :, :Dm], xwT[:, :, :2 * Cx], dtwT[:, :, :Dm]) + ((dtw_io[:, :, :R],) if want_dtw_io else ())
         ctx.mark_non_differentiable(*outs)

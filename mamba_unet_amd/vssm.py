@@ -153,8 +153,26 @@ class VSSM(nn.Module):
             nn.init.constant_(m.bias, 0)
             nn.init.constant_(m.weight, 1.0)
 
+    def _draw_stochastic_depth(self, x):
+        """The per-sample keep masks of every VSSBlock of this forward (timm's DropPath, mamba_sys.py:581) from ONE Bernoulli
+        draw: (blocks, batch) with each block's own keep probability, scaled by 1 / keep in the residual stream's dtype."""
+        from .ss2d import DropPath
+        live = [(blk, stage.use_checkpoint) for stage in (*self.layers, *self.layers_up) if hasattr(stage, "blocks") for blk in stage.blocks
+                if type(blk.drop_path) is DropPath and blk.drop_path.training and blk.drop_path.drop_prob > 0.0]
+        if not live or not x.is_cuda or os.environ.get("SS2D_NO_DP_PREDRAW"):     # (A/B switch: every block draws its own)
+            return
+        key = (x.device, tuple(blk.drop_path.drop_prob for blk, _ in live))
+        if getattr(self, "_dp_key", None) != key:
+            self._dp_key, self._dp_keep_prob = key, torch.tensor([1.0 - q for q in key[1]], device=x.device).view(-1, 1)
+        keep = self._dp_keep_prob
+        scale = torch.bernoulli(keep.expand(len(live), x.shape[0])).div_(keep).to(x.dtype)
+        for i, (blk, ckpt) in enumerate(live):
+            blk._dp_scale, blk._dp_keep = scale[i], bool(ckpt)
+
     def forward_features(self, x):
         x = self.patch_embed(x)
+        if self.training:
+            self._draw_stochastic_depth(x)
         skips = []
         for layer in self.layers:
             skips.append(x)

@@ -248,6 +248,48 @@ def test_layer_norm_kernel(rows_shape, D, dtype, autocast):
     assert rel_l2(wd.grad.cpu(), wr.grad) < 2e-5 and rel_l2(bd.grad.cpu(), br.grad) < 2e-5
 
 
+@pytest.mark.parametrize("rows_shape,D,dtype,autocast", [((2, 56, 56), 96, torch.float32, False), ((3, 7, 7), 1536, torch.float32, False),
+                                                          ((777,), 20, torch.float32, False), ((2, 28, 28), 384, torch.bfloat16, False),
+                                                          ((2, 28, 28), 192, torch.float32, True)])
+def test_layer_norm_skip_adds_the_residual_gradient(rows_shape, D, dtype, autocast):
+    """x + f(LN(x)) (VSSBlock, mamba_sys.py:583-585) with x's residual gradient added inside the LayerNorm backward kernel
+    (ss2d_layernorm_bwd_add) instead of by autograd's accumulation: against torch fp64 on `3 * x + LN(x) * m`."""
+    from mamba_unet_amd.ss2d_ops import apply_norm_skip
+    gen = torch.Generator().manual_seed(D + 7)
+    x = (torch.randn(*rows_shape, D, generator=gen) * 1.7 - 0.2).to(dtype)
+    m = torch.randn(*rows_shape, D, generator=gen).to(torch.bfloat16 if autocast else dtype)
+    go = torch.randn(*rows_shape, D, generator=gen).to(dtype)
+    ln = torch.nn.LayerNorm(D)
+    with torch.no_grad():
+        ln.weight.copy_(torch.rand(D, generator=gen) + 0.5)
+        ln.bias.copy_(torch.randn(D, generator=gen) * 0.1)
+    lr = torch.nn.LayerNorm(D).double()
+    lr.load_state_dict(ln.state_dict())
+    xr = x.double().requires_grad_(True)
+    ref = 3.0 * xr + lr(xr) * m.double()
+    ref.backward(go.double())
+    ld, xd = ln.cuda(), x.cuda().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+        y, skip = apply_norm_skip(ld, xd)
+    assert skip.data_ptr() == xd.data_ptr() and skip.dtype == dtype
+    out = 3.0 * skip + (y * m.cuda()).to(dtype)
+    out.backward(go.cuda())
+    tol = 1e-5 if (dtype == torch.float32 and not autocast) else 1e-2
+    assert xd.grad.dtype == dtype and rel_l2(xd.grad.float().cpu(), xr.grad) < tol
+    assert rel_l2(ld.weight.grad.cpu(), lr.weight.grad) < (2e-5 if not autocast and dtype == torch.float32 else 1e-2)
+    # the pass-through output alone, and the norm output alone
+    x2 = x.cuda().requires_grad_(True)
+    y2, s2 = apply_norm_skip(ld, x2)
+    (s2 * 2.0).sum().backward()
+    assert torch.equal(x2.grad.cpu(), torch.full_like(x, 2.0))
+    x3 = x.cuda().requires_grad_(True)
+    y3, _ = apply_norm_skip(ld, x3)
+    y3.backward(go.cuda().to(y3.dtype))
+    x4 = x.double().requires_grad_(True)
+    lr(x4).backward(go.double())
+    assert rel_l2(x3.grad.float().cpu(), x4.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
 def test_linear_with_bias_matches_f_linear():
     from mamba_unet_amd.ss2d_ops import linear
     gen = torch.Generator().manual_seed(5)
