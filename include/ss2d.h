@@ -135,6 +135,15 @@ int ss2d_selective_scan_core_bwd(int dtype, const void *u, const void *x_dbl, co
                                  float *dB, float *dC, float *dD, float *ddelta_bias, int batch, int dim, int L, int dstate,
                                  int ngroups, int dt_rank, int u_groups, unsigned rev_mask, void *workspace,
                                  size_t workspace_bytes, void *stream);
+/* _packed: the same backward with dB / dC written where their consumer wants them: as rows [dt_rank, dt_rank + 2*dstate) of
+ * every (batch, group) block of d_x_dbl, the gradient of the x_proj output (same layout and `dtype` as x_dbl; rows
+ * [0, dt_rank) -- d_dts -- are the caller's to fill, e.g. with ss2d_chan_gemm writing in place).  No fp32 dB / dC tensors
+ * and no packing pass (ss2d_xdbl_grad_pack).  No counterpart in the reference (autograd of torch.split, mamba_sys.py:417). */
+int ss2d_selective_scan_core_bwd_packed(int dtype, const void *u, const void *x_dbl, const float *dt_w, const float *A,
+                                        const float *D, const float *delta_bias, const void *dout, const float *ckpt, void *du,
+                                        void *ddelta, float *dA, void *d_x_dbl, float *dD, float *ddelta_bias, int batch, int dim,
+                                        int L, int dstate, int ngroups, int dt_rank, int u_groups, unsigned rev_mask,
+                                        void *workspace, size_t workspace_bytes, void *stream);
 
 /* CrossScan (mamba_sys.py:403-404): x (B, D, H, W) -> xs (B, 4, D, H*W); _bwd is its adjoint
  * (sums the four directions back into dx). */

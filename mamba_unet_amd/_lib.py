@@ -26,6 +26,7 @@ _SIGNATURES = {
     "ss2d_selective_scan_dir_bwd_static": (_i, [_i] + [_vp] * 18 + [_i] * 7 + [ctypes.c_uint, ctypes.c_longlong, _vp]),
     "ss2d_selective_scan_core_fwd": (_i, [_i] + [_vp] * 8 + [_i] * 7 + [ctypes.c_uint, _vp]),
     "ss2d_selective_scan_core_bwd": (_i, [_i] + [_vp] * 15 + [_i] * 7 + [ctypes.c_uint, _vp, _sz, _vp]),
+    "ss2d_selective_scan_core_bwd_packed": (_i, [_i] + [_vp] * 14 + [_i] * 7 + [ctypes.c_uint, _vp, _sz, _vp]),
     "ss2d_cross_scan_fwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ss2d_cross_scan_bwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _vp]),
     "ss2d_cross_merge_fwd": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp]),

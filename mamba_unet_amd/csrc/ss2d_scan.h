@@ -16,6 +16,8 @@ struct ScanBwdParams {
     float *ws;           // state-row kernel: partial dB/dC tiles (one per workgroup and (batch, group) it touches), or null = atomics
     const float *dtw;    // fused-delta form (null otherwise): dt_proj weight (dim, R); `delta` then points at the dts rows (R, L) of
     int R;               // every (batch, group) block (block stride bc_stride) and delta = dtw . dts is recomputed in the kernel
+    void *dxdbl;         // fused-delta form, nullable: the gradient of the x_proj output (IO type, x_dbl's layout); the reduction pass
+                         // then writes dB | dC as rows [R, R + 32) of every block instead of the fp32 dB / dC tensors
 };
 
 // The state-row backward (ss2d_scan_bwd_sr.hip): dstate == 16, no z.  Returns a hipError_t / 0.

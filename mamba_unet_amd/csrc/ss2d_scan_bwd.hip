@@ -409,7 +409,7 @@ static int scan_bwd_impl(int dtype, const void *u, const void *delta, const floa
                          const void *z, const float *delta_bias, const void *dout, const float *ckpt, void *du, void *ddelta,
                          float *dA, float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch, int dim, int L,
                          int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask, long long bc_bg_stride,
-                         void *workspace, size_t workspace_bytes, const float *dt_w, int dt_rank, void *stream);
+                         void *workspace, size_t workspace_bytes, const float *dt_w, int dt_rank, void *d_xdbl, void *stream);
 
 extern "C" int ss2d_selective_scan_dir_bwd_ws(int dtype, const void *u, const void *delta, const float *A, const void *B,
                                               const void *C, const float *D, const void *z, const float *delta_bias,
@@ -419,7 +419,29 @@ extern "C" int ss2d_selective_scan_dir_bwd_ws(int dtype, const void *u, const vo
                                               unsigned rev_mask, long long bc_bg_stride, void *workspace,
                                               size_t workspace_bytes, void *stream) {
     return scan_bwd_impl(dtype, u, delta, A, B, C, D, z, delta_bias, dout, ckpt, du, ddelta, dA, dB, dC, dD, dz, ddelta_bias, batch, dim,
-                         L, dstate, ngroups, delta_softplus, u_groups, rev_mask, bc_bg_stride, workspace, workspace_bytes, nullptr, 0, stream);
+                         L, dstate, ngroups, delta_softplus, u_groups, rev_mask, bc_bg_stride, workspace, workspace_bytes, nullptr, 0, nullptr, stream);
+}
+
+static int core_bwd_impl(const char *name, int dtype, const void *u, const void *x_dbl, const float *dt_w, const float *A,
+                         const float *D, const float *delta_bias, const void *dout, const float *ckpt, void *du,
+                         void *ddelta, float *dA, float *dB, float *dC, void *d_xdbl, float *dD, float *ddelta_bias, int batch,
+                         int dim, int L, int dstate, int ngroups, int dt_rank, int u_groups, unsigned rev_mask,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    if (!x_dbl || !dt_w) { ss2d_set_error("%s: null required pointer", name); return -2; }
+    if (dt_rank != 6 && dt_rank != 12) { ss2d_set_error("%s: dt_rank %d is not 6 or 12", name, dt_rank); return -4; }
+    if (dstate != 16 || L % 4) { ss2d_set_error("%s: needs dstate == 16 and L %% 4 == 0 (got %d, %d)", name, dstate, L); return -4; }
+    if (force_general_kernel()) { ss2d_set_error("%s: not available with SS2D_BWD_KERNEL=general", name); return -7; }
+    const size_t need = ss2d_scan_bwd_workspace_bytes(batch, dim, L, dstate, ngroups);
+    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
+        ss2d_set_error("%s: needs a 16-byte aligned workspace of %zu bytes", name, need); return -7; }
+    if ((((uintptr_t)dB | (uintptr_t)dC | (uintptr_t)d_xdbl | (uintptr_t)A | (uintptr_t)ckpt) & 15) != 0) {
+        ss2d_set_error("%s: A, ckpt, dB, dC / d_x_dbl must be 16-byte aligned", name); return -7; }
+    const size_t es = dtype == SS2D_DTYPE_BF16 ? 2 : 4;
+    const char *base = static_cast<const char *>(x_dbl);
+    const long long stride = (long long)(dt_rank + 2 * dstate) * L;
+    return scan_bwd_impl(dtype, u, x_dbl, A, base + (size_t)dt_rank * L * es, base + (size_t)(dt_rank + dstate) * L * es, D, nullptr,
+                         delta_bias, dout, ckpt, du, ddelta, dA, dB, dC, dD, nullptr, ddelta_bias, batch, dim, L, dstate, ngroups, 1,
+                         u_groups, rev_mask, stride, workspace, workspace_bytes, dt_w, dt_rank, d_xdbl, stream);
 }
 
 extern "C" int ss2d_selective_scan_core_bwd(int dtype, const void *u, const void *x_dbl, const float *dt_w, const float *A,
@@ -427,30 +449,29 @@ extern "C" int ss2d_selective_scan_core_bwd(int dtype, const void *u, const void
                                             void *ddelta, float *dA, float *dB, float *dC, float *dD, float *ddelta_bias, int batch,
                                             int dim, int L, int dstate, int ngroups, int dt_rank, int u_groups, unsigned rev_mask,
                                             void *workspace, size_t workspace_bytes, void *stream) {
-    if (!x_dbl || !dt_w) { ss2d_set_error("selective_scan_core_bwd: null required pointer"); return -2; }
-    if (dt_rank != 6 && dt_rank != 12) { ss2d_set_error("selective_scan_core_bwd: dt_rank %d is not 6 or 12", dt_rank); return -4; }
-    if (dstate != 16 || L % 4) { ss2d_set_error("selective_scan_core_bwd: needs dstate == 16 and L %% 4 == 0 (got %d, %d)", dstate, L); return -4; }
-    if (force_general_kernel()) { ss2d_set_error("selective_scan_core_bwd: not available with SS2D_BWD_KERNEL=general"); return -7; }
-    const size_t need = ss2d_scan_bwd_workspace_bytes(batch, dim, L, dstate, ngroups);
-    if (!workspace || workspace_bytes < need || ((uintptr_t)workspace & 15)) {
-        ss2d_set_error("selective_scan_core_bwd: needs a 16-byte aligned workspace of %zu bytes", need); return -7; }
-    if ((((uintptr_t)dB | (uintptr_t)dC | (uintptr_t)A | (uintptr_t)ckpt) & 15) != 0) {
-        ss2d_set_error("selective_scan_core_bwd: A, ckpt, dB, dC must be 16-byte aligned"); return -7; }
-    const size_t es = dtype == SS2D_DTYPE_BF16 ? 2 : 4;
-    const char *base = static_cast<const char *>(x_dbl);
-    const long long stride = (long long)(dt_rank + 2 * dstate) * L;
-    return scan_bwd_impl(dtype, u, x_dbl, A, base + (size_t)dt_rank * L * es, base + (size_t)(dt_rank + dstate) * L * es, D, nullptr,
-                         delta_bias, dout, ckpt, du, ddelta, dA, dB, dC, dD, nullptr, ddelta_bias, batch, dim, L, dstate, ngroups, 1,
-                         u_groups, rev_mask, stride, workspace, workspace_bytes, dt_w, dt_rank, stream);
+    if (!dB || !dC) { ss2d_set_error("selective_scan_core_bwd: null required pointer"); return -2; }
+    return core_bwd_impl("selective_scan_core_bwd", dtype, u, x_dbl, dt_w, A, D, delta_bias, dout, ckpt, du, ddelta, dA, dB, dC, nullptr,
+                         dD, ddelta_bias, batch, dim, L, dstate, ngroups, dt_rank, u_groups, rev_mask, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ss2d_selective_scan_core_bwd_packed(int dtype, const void *u, const void *x_dbl, const float *dt_w, const float *A,
+                                                   const float *D, const float *delta_bias, const void *dout, const float *ckpt,
+                                                   void *du, void *ddelta, float *dA, void *d_x_dbl, float *dD, float *ddelta_bias,
+                                                   int batch, int dim, int L, int dstate, int ngroups, int dt_rank, int u_groups,
+                                                   unsigned rev_mask, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!d_x_dbl) { ss2d_set_error("selective_scan_core_bwd_packed: null required pointer"); return -2; }
+    return core_bwd_impl("selective_scan_core_bwd_packed", dtype, u, x_dbl, dt_w, A, D, delta_bias, dout, ckpt, du, ddelta, dA, nullptr,
+                         nullptr, d_x_dbl, dD, ddelta_bias, batch, dim, L, dstate, ngroups, dt_rank, u_groups, rev_mask, workspace,
+                         workspace_bytes, stream);
 }
 
 static int scan_bwd_impl(int dtype, const void *u, const void *delta, const float *A, const void *B, const void *C, const float *D,
                          const void *z, const float *delta_bias, const void *dout, const float *ckpt, void *du, void *ddelta,
                          float *dA, float *dB, float *dC, float *dD, void *dz, float *ddelta_bias, int batch, int dim, int L,
                          int dstate, int ngroups, int delta_softplus, int u_groups, unsigned rev_mask, long long bc_bg_stride,
-                         void *workspace, size_t workspace_bytes, const float *dt_w, int dt_rank, void *stream) {
+                         void *workspace, size_t workspace_bytes, const float *dt_w, int dt_rank, void *d_xdbl, void *stream) {
     if (dtype != SS2D_DTYPE_F32 && dtype != SS2D_DTYPE_BF16) { ss2d_set_error("selective_scan_bwd: unknown dtype %d", dtype); return -1; }
-    if (!u || !delta || !A || !B || !C || !dout || !ckpt || !du || !ddelta || !dA || !dB || !dC) {
+    if (!u || !delta || !A || !B || !C || !dout || !ckpt || !du || !ddelta || !dA || ((!dB || !dC) && !d_xdbl)) {
         ss2d_set_error("selective_scan_bwd: null required pointer"); return -2; }
     if ((z != nullptr) != (dz != nullptr)) { ss2d_set_error("selective_scan_bwd: z and dz must be given together"); return -2; }
     if (batch <= 0 || dim <= 0 || L <= 0 || dstate <= 0 || ngroups <= 0) { ss2d_set_error("selective_scan_bwd: non-positive size"); return -3; }
@@ -463,7 +484,7 @@ static int scan_bwd_impl(int dtype, const void *u, const void *delta, const floa
     if (bc_bg_stride < bc_dense) { ss2d_set_error("selective_scan_bwd: bc_bg_stride %lld < dstate*L", bc_bg_stride); return -5; }
     ScanBwdParams p;
     p.Gu = u_groups; p.rev_mask = rev_mask; p.bc_stride = bc_bg_stride;
-    p.dtw = dt_w; p.R = dt_rank; p.ws = nullptr; p.rows_per_wg = 0;
+    p.dtw = dt_w; p.R = dt_rank; p.ws = nullptr; p.rows_per_wg = 0; p.dxdbl = d_xdbl;
     p.u = u; p.delta = delta; p.A = A; p.B = B; p.C = C;
     p.D = D; p.z = z; p.bias = delta_bias; p.dout = dout; p.ckpt = ckpt;
     p.du = du; p.ddelta = ddelta; p.dA = dA; p.dB = dB; p.dC = dC; p.dD = D ? dD : nullptr;
@@ -513,6 +534,7 @@ static int scan_bwd_impl(int dtype, const void *u, const void *delta, const floa
         if (rc) ss2d_set_error("selective_scan_bwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
         return rc;
     }
+    if (d_xdbl) { ss2d_set_error("selective_scan_core_bwd_packed: this shape is outside the state-row kernel (L %d)", L); return -7; }
     if (dt_w) { ss2d_set_error("selective_scan_core_bwd: A and ckpt must be 16-byte aligned"); return -7; }
     int rc = dtype == SS2D_DTYPE_BF16
                  ? (dirs ? launch_bwd_nw<bf16, true>(nw, p, z != nullptr, vec4, lds, s) : launch_bwd_nw<bf16, false>(nw, p, z != nullptr, vec4, lds, s))

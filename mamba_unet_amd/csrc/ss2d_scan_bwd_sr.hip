@@ -483,6 +483,22 @@ __global__ __launch_bounds__(256) void scan_bwd_sr_reduce_kernel(const float *__
     *reinterpret_cast<f4 *>(dst) = acc;
 }
 
+// The same sum written as rows [R, R + 32) of every (batch, group) block of the x_proj output's gradient, in its storage
+// type: the B | C rows of a block are one contiguous run of 32 * L elements there, so the fp32 dB / dC tensors and the pass
+// that packed them (with d_dts) into that gradient are not needed.
+template <typename IO>
+__global__ __launch_bounds__(256) void scan_bwd_sr_reduce_packed_kernel(const float *__restrict__ ws, IO *__restrict__ dxdbl, long long bcs, int R,
+                                                                        int L, int dpg, int rows_per_wg, int n4) {
+    const int nblk = (n4 + 255) / 256, bg = blockIdx.x / nblk;
+    const int i = (blockIdx.x - bg * nblk) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const long long r_lo = (long long)bg * dpg, r_hi = r_lo + dpg - 1;
+    const int w0 = (int)(r_lo / rows_per_wg), w1 = (int)(r_hi / rows_per_wg);
+    f4 acc = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int w = w0; w <= w1; ++w) acc += *reinterpret_cast<const f4 *>(ws + ((size_t)w + bg) * 32 * (size_t)L + 4 * (size_t)i);
+    st4(dxdbl + (size_t)bg * bcs + (size_t)R * L + 4 * (size_t)i, acc);
+}
+
 template <bool VEC, typename IO, bool DIRS, bool WS, int DTR = 0>
 int launch_sr(const ScanBwdParams &p, int nwg, hipStream_t s) {
     auto kern = scan_bwd_sr_kernel<VEC, IO, DIRS, WS, DTR>;
@@ -565,7 +581,7 @@ int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, fl
     const long long nwg = (total + per - 1) / per;
     if (nwg > 0x7fffffffLL) return (int)hipErrorInvalidConfiguration;
     // the partial-tile path needs 16-byte rows (L % 4) for its reduction kernel and a big enough, aligned workspace
-    p.ws = (ws && (p.L % 4 == 0) && (((uintptr_t)ws | (uintptr_t)p.dB | (uintptr_t)p.dC) & 15) == 0 &&
+    p.ws = (ws && (p.L % 4 == 0) && (((uintptr_t)ws | (uintptr_t)p.dB | (uintptr_t)p.dC | (uintptr_t)p.dxdbl) & 15) == 0 &&
             ws_bytes >= ss2d_scan_bwd_sr_ws_bytes(p.batch, p.dim, p.L, p.G)) ? ws : nullptr;
     int rc;
     if (p.dtw) {   // fused delta: only the form SS2D issues (4-element rows, direction-aware, workspace), ranks 6 and 12
@@ -584,6 +600,12 @@ int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, fl
     const int n4 = 8 * p.L;   // float4s per (dB | dC) tile
     const float *wsc = p.ws;
     int L = p.L, dpg = p.dpg, rpw = p.rows_per_wg, n4v = n4;
+    if (p.dxdbl) {
+        const dim3 grid((unsigned)((n4 + 255) / 256) * (unsigned)(p.batch * p.G));
+        if (dtype == SS2D_DTYPE_BF16) ss2d_launch(scan_bwd_sr_reduce_packed_kernel<bf16>, grid, dim3(256), 0, s, wsc, static_cast<bf16 *>(p.dxdbl), p.bc_stride, p.R, L, dpg, rpw, n4v);
+        else ss2d_launch(scan_bwd_sr_reduce_packed_kernel<float>, grid, dim3(256), 0, s, wsc, static_cast<float *>(p.dxdbl), p.bc_stride, p.R, L, dpg, rpw, n4v);
+        return ss2d_take_launch_rc();
+    }
     void *args[] = {&wsc, &p.dB, &p.dC, &L, &dpg, &rpw, &n4v};
     return (int)hipLaunchKernel(reinterpret_cast<const void *>(scan_bwd_sr_reduce_kernel), dim3((unsigned)((n4 + 255) / 256) * (unsigned)(p.batch * p.G)), dim3(256), args, 0, s);
 }

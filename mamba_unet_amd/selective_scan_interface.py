@@ -250,6 +250,8 @@ class ScanCoreFn(torch.autograd.Function):
 
     # class-wide switch (A/B runs; env SS2D_NO_FUSE_DELTA=1): compute delta inside the scan kernels for dt_rank 6 / 12
     FUSE_DELTA = not _os.environ.get("SS2D_NO_FUSE_DELTA")
+    # (A/B; env SS2D_NO_PACKED_DXDBL=1): the backward's reduction pass writes dB | dC into the x_proj gradient's rows
+    PACKED_DXDBL = not _os.environ.get("SS2D_NO_PACKED_DXDBL")
 
     @staticmethod
     def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None, dtwT=None, dtw_io=None):
@@ -326,8 +328,9 @@ class ScanCoreFn(torch.autograd.Function):
         du = torch.empty((batch, dim, L), device=dev, dtype=io)
         ddelta = torch.empty_like(du)
         sh = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
+        packed = ctx.fused_delta and ScanCoreFn.PACKED_DXDBL     # dB | dC written straight into d_xdbl's rows by the reduction pass
         dA, dD, dbias, dB, dC, ws, wsb = _bwd_buffers(lib, dev, batch, dim, L, N, 4, False, sh(A), sh(D), sh(bias),
-                                                       (batch, 4, N, L), (batch, 4, N, L))
+                                                       (0,) if packed else (batch, 4, N, L), (0,) if packed else (batch, 4, N, L))
         if ctx.fused_delta:
             B_ = C_ = None
         elif (Cx * L) % 4 == 0:
@@ -338,7 +341,13 @@ class ScanCoreFn(torch.autograd.Function):
         with _lib.on_device(dev):
             rc = lib.ss2d_dirs_scatter_ld(code, 2, _lib.ptr(g), _lib.ptr(dys2), batch, Dch, H, W, 1, L, _stream())
             _lib.check(rc, "ss2d_dirs_scatter_ld")
-            if ctx.fused_delta:
+            if packed:
+                rc = lib.ss2d_selective_scan_core_bwd_packed(code, _lib.ptr(u), _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(A), _lib.ptr(D),
+                                                             _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du), _lib.ptr(ddelta),
+                                                             _lib.ptr(dA), _lib.ptr(d_xdbl), _lib.ptr(dD), _lib.ptr(dbias), batch, dim,
+                                                             L, N, 4, R, ScanMergeFn.U_GROUPS, ScanMergeFn.REV_MASK, _lib.ptr(ws), wsb, _stream())
+                _lib.check(rc, "ss2d_selective_scan_core_bwd_packed")
+            elif ctx.fused_delta:
                 rc = lib.ss2d_selective_scan_core_bwd(code, _lib.ptr(u), _lib.ptr(xd), _lib.ptr(w32), _lib.ptr(A), _lib.ptr(D),
                                                       _lib.ptr(bias), _lib.ptr(dys2), _lib.ptr(ckpt), _lib.ptr(du), _lib.ptr(ddelta),
                                                       _lib.ptr(dA), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(dD), _lib.ptr(dbias), batch, dim,
@@ -367,7 +376,8 @@ class ScanCoreFn(torch.autograd.Function):
                 dd4 = ddelta.view(batch, 4, Dch, L)
                 # d_dts (b, 4, R, l) = dt_w^T . ddelta.  bf16: the own channel-major MFMA kernel; the library's batched GEMM first
                 # materialises the weight once per batch entry (a (b, 4, R, d) copy: 5-26 us per call on top of the product)
-                d_dts = chan_gemm(dtwT, dd4, padded=True) if dtwT is not None else chan_gemm(w32.transpose(1, 2), dd4)
+                dts_rows = d_xdbl[:, :, :R] if packed else None          # the d_dts rows of the x_proj output's gradient, written in place
+                d_dts = chan_gemm(dtwT, dd4, padded=True, out=dts_rows) if dtwT is not None else chan_gemm(w32.transpose(1, 2), dd4, out=dts_rows)
                 if d_dts is None:
                     d_dts = torch.matmul(w32.to(io).transpose(1, 2).unsqueeze(0), dd4).contiguous()
                 # (4, d, R): own MFMA kernel (bf16 25 / 19 / 13 us at stages 0-2 against the library's 61 / 42 / 28, fp32 -- as
@@ -376,8 +386,11 @@ class ScanCoreFn(torch.autograd.Function):
                 d_w = chan_wgrad(dd4, xd[:, :, :R])
                 if d_w is None:
                     d_w = torch.matmul(dd4, xd[:, :, :R].transpose(2, 3)).sum(0, dtype=torch.float32)
-            rc = lib.ss2d_xdbl_grad_pack(code, _lib.ptr(d_dts), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(d_xdbl), batch * 4, R, N, L, _stream())
-            _lib.check(rc, "ss2d_xdbl_grad_pack")
+            if not packed:
+                rc = lib.ss2d_xdbl_grad_pack(code, _lib.ptr(d_dts), _lib.ptr(dB), _lib.ptr(dC), _lib.ptr(d_xdbl), batch * 4, R, N, L, _stream())
+                _lib.check(rc, "ss2d_xdbl_grad_pack")
+            elif d_dts is not dts_rows:        # the GEMM did not take the in-place path
+                dts_rows.copy_(d_dts)
         cast = lambda t, d: None if t is None else t.to(d)  # noqa: E731
         return (cast(du2, u_dt), cast(d_xdbl, xdbl_dt), cast(d_w, w_dt), cast(dA, A_dt), cast(dD, D_dt), cast(dbias, b_dt),
                 None, None, cast(dx, x_dt), None, None, None)

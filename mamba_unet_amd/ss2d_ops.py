@@ -233,12 +233,13 @@ def chan_wgrad(P: torch.Tensor, Q: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def chan_gemm(W: torch.Tensor, X: torch.Tensor, padded: bool = False):
+def chan_gemm(W: torch.Tensor, X: torch.Tensor, padded: bool = False, out=None):
     """Y (B, G, M, L) = W (G, M, K) @ X (B, G, K, L) for a channel-major X (bf16 or fp32) whose rows are L apart (row ranges
     of wider blocks are fine): x_proj, dt_proj and their input gradients (mamba_sys.py:407, :420) on the MFMA kernels of
     csrc/ss2d_cmgemm.hip (fp32: three-way bf16 split, fp32 results).  Y has X's dtype.  None when dtype or layout do not
     qualify (the caller then uses the BLAS library).  `padded`: W is a (G, M, K) view of a buffer in X's dtype whose rows
-    are already padded with zeros to a multiple of 16 bytes (block_params): used in place, no cast / pad launches."""
+    are already padded with zeros to a multiple of 16 bytes (block_params): used in place, no cast / pad launches.
+    `out`: a (B, G, M, L) view (rows contiguous and L apart, e.g. row ranges of wider blocks) that receives Y."""
     _need_gpu(X, "chan_gemm")
     B, G, K, L = X.shape
     M = W.shape[1]
@@ -257,10 +258,16 @@ def chan_gemm(W: torch.Tensor, X: torch.Tensor, padded: bool = False):
         Wp = W.to(X.dtype)
         Wp = torch.nn.functional.pad(Wp, (0, ldw - K)) if ldw != K else Wp.contiguous()
         swg = M * ldw
-    Y = torch.empty((B, G, M, L), device=X.device, dtype=X.dtype)
+    if out is not None:
+        if (tuple(out.shape) != (B, G, M, L) or out.dtype != X.dtype or out.stride(3) != 1 or out.stride(2) != L or out.stride(0) % 4
+                or out.stride(1) % 4 or out.data_ptr() % (16 if f32 else 8)):
+            return None
+        Y = out
+    else:
+        Y = torch.empty((B, G, M, L), device=X.device, dtype=X.dtype)
     with _lib.on_device(X.device):
         rc = _lib.load().ss2d_chan_gemm(_F32 if f32 else _BF16, _lib.ptr(Wp), _lib.ptr(X), _lib.ptr(Y), B, G, M, K, ldw, L, swg,
-                                        X.stride(0), X.stride(1), G * M * L, M * L, _stream())
+                                        X.stride(0), X.stride(1), Y.stride(0), Y.stride(1), _stream())
     _lib.check(rc, "ss2d_chan_gemm")
     return Y
 

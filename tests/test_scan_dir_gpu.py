@@ -202,3 +202,36 @@ def test_fused_delta_matches_materialised_delta(B, D, H, W, R, dtype):
     for name, a, b in zip(("y", "dx", "dx_dbl", "ddt_w", "dA", "dD", "dbias"), *res):
         err = rel_l2(a.float().cpu(), b.float().cpu())
         assert err < tol, (name, err)
+
+
+@pytest.mark.parametrize("B,D,H,W,R,dtype", [(2, 32, 28, 28, 6, torch.float32), (2, 64, 28, 28, 12, torch.bfloat16), (3, 20, 12, 20, 6, torch.bfloat16)])
+def test_packed_x_dbl_gradient_equals_the_packing_pass(B, D, H, W, R, dtype):
+    """ss2d_selective_scan_core_bwd_packed (the reduction pass writes dB | dC into rows [R, R + 2N) of the x_proj gradient, the
+    d_dts GEMM writes rows [0, R) in place) against ss2d_selective_scan_core_bwd + ss2d_xdbl_grad_pack: dx and d x_dbl bit for
+    bit (the same sums, the same single rounding to the storage type); the atomically accumulated parameter gradients to 1e-6."""
+    from mamba_unet_amd import scan_core_fn
+    from mamba_unet_amd.selective_scan_interface import ScanCoreFn
+    L, N = H * W, 16
+    gen = torch.Generator().manual_seed(L + 3 * R)
+    r = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    x = r(B, D, H, W).cuda().to(dtype)
+    x_dbl = torch.cat([r(B, 4, R, L) * 0.5, r(B, 4, 2 * N, L)], 2).cuda().to(dtype)
+    dt_w = (r(4, D, R) * 0.3).cuda()
+    A, Dv, bias = -torch.exp(r(4 * D, N) * 0.5).cuda(), (torch.rand(4 * D, generator=gen) + 0.5).cuda(), (r(4 * D) * 0.2 - 2.0).cuda()
+    gy = r(B, H, W, D).cuda().to(dtype)
+    xs2 = torch.stack([x.reshape(B, D, L), x.transpose(2, 3).reshape(B, D, L)], 1).reshape(B, 2 * D, L)
+    res = []
+    try:
+        for packed in (True, False):
+            ScanCoreFn.PACKED_DXDBL = packed
+            leaves = [t.clone().requires_grad_(True) for t in (x, x_dbl, dt_w, A, Dv, bias)]
+            y = scan_core_fn(xs2, leaves[1], leaves[2], leaves[3], leaves[4], leaves[5], H, W, x=leaves[0])
+            y.backward(gy)
+            res.append([t.grad for t in leaves])
+    finally:
+        ScanCoreFn.PACKED_DXDBL = True
+    for name, a, b in zip(("dx", "dx_dbl", "ddt_w", "dA", "dD", "dbias"), *res):
+        if name in ("ddt_w", "dA", "dD", "dbias"):     # float atomics: order-dependent in the last bit
+            assert rel_l2(a.float().cpu(), b.float().cpu()) < 1e-6, name
+        else:
+            assert torch.equal(a, b), name
