@@ -263,6 +263,17 @@ int ss2d_outnorm_gate_fwd(int dtype, const void *y, const void *z, const float *
 int ss2d_outnorm_gate_bwd(int dtype, const void *dout, const void *y, const void *z, const float *gamma,
                           const float *beta, const float *mean, const float *rstd, void *dy, void *dz, float *dgamma,
                           float *dbeta, long long rows, int D, int ldz, int lddz, void *stream);
+/* The same pair with a per-sample factor folded in: out (forward) and dout (backward) of row r are multiplied by
+ * row_scale[r / rows_per_scale] (fp32; null = 1).  This is where the block's stochastic-depth factor mask / keep
+ * (timm DropPath around the branch, mamba_sys.py:581-585) is applied: out_proj has no bias, so scaling its input equals
+ * scaling its output, and the pass that multiplied the branch (and the one that multiplied its gradient) disappears. */
+int ss2d_outnorm_gate_scaled_fwd(int dtype, const void *y, const void *z, const float *gamma, const float *beta,
+                                 const float *row_scale, long long rows_per_scale, void *out, float *mean, float *rstd,
+                                 long long rows, int D, int ldz, float eps, void *stream);
+int ss2d_outnorm_gate_scaled_bwd(int dtype, const void *dout, const void *y, const void *z, const float *gamma,
+                                 const float *beta, const float *mean, const float *rstd, const float *row_scale,
+                                 long long rows_per_scale, void *dy, void *dz, float *dgamma, float *dbeta, long long rows,
+                                 int D, int ldz, int lddz, void *stream);
 
 /* LayerNorm over the last axis, eps inside the sqrt: the `ln_1` of VSSBlock (mamba_sys.py:573-585) and the norms
  * of PatchMerging2D / PatchExpand / FinalPatchExpand_X4 (:196, :226, :249).  x, dx: (rows, D) in `in_dtype`;

@@ -48,6 +48,8 @@ _SIGNATURES = {
     "ss2d_linear_wgrad": (_i, [_i, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _vp]),
     "ss2d_outnorm_gate_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, ctypes.c_float, _vp]),
     "ss2d_outnorm_gate_bwd": (_i, [_i] + [_vp] * 11 + [ctypes.c_longlong, _i, _i, _i, _vp]),
+    "ss2d_outnorm_gate_scaled_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, ctypes.c_float, _vp]),
+    "ss2d_outnorm_gate_scaled_bwd": (_i, [_i] + [_vp] * 8 + [ctypes.c_longlong] + [_vp] * 4 + [ctypes.c_longlong, _i, _i, _i, _vp]),
     "ss2d_layernorm_fwd": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_float, _vp]),
     "ss2d_layernorm_bwd": (_i, [_i, _i] + [_vp] * 8 + [ctypes.c_longlong, _i, _vp]),
     "ss2d_layernorm_bwd_add": (_i, [_i, _i] + [_vp] * 9 + [ctypes.c_longlong, _i, _vp]),

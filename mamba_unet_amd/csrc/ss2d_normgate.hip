@@ -22,7 +22,9 @@ struct NormGateParams {
     long long rows;
     int D, ldz, lddz;
     float eps;
-};
+    const float *rscale;    // nullable: out (and, in the backward, dout) of row r is multiplied by rscale[r / rps] -- the per-sample
+    unsigned rps;           // stochastic-depth factor mask / keep of the block (mamba_sys.py:581-585), applied here, in front of the
+};                          // bias-free out_proj, instead of in a pass of its own behind it
 
 __device__ __forceinline__ float wave_sum(float v) { return lanes_sum<64>(v); }
 
@@ -64,6 +66,7 @@ __global__ __launch_bounds__(256) void normgate_fwd_kernel(const NormGateParams 
         }
         const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * invD + p.eps);
         if (lane == 0 && p.mean) { p.mean[r] = mu; p.rstd[r] = rstd; }
+        const float sc = p.rscale ? p.rscale[(unsigned)r / p.rps] : 1.0f;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + 64 * k;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void normgate_fwd_kernel(const NormGateParams 
                 for (int e = 0; e < 4; ++e) {
                     const float v = (yv[k][e] - mu) * rstd * g[k][e] + b[k][e];
                     const float zz = zv[k][e];
-                    o[e] = v * (zz * sigmoidf_fast(zz));
+                    o[e] = v * (zz * sigmoidf_fast(zz)) * sc;
                 }
                 st4(O + r * D + 4 * c, o);
             }
@@ -106,11 +109,13 @@ __global__ __launch_bounds__(NWV * 64) void normgate_bwd_kernel(const NormGatePa
     // 14 x 14 stage, 18 at 56 x 56) and every trip used to start with an exposed memory round trip -- 21 us whatever the size.
     // Loads are never under a branch: chunks past D and rows past the end read a clamped address and are not used.
     f4 yv[K], zv[K], gv[K];
-    float mu = 0.0f, rstd = 0.0f;
-    auto fetch = [&](long long r_, f4 (&y_)[K], f4 (&z_)[K], f4 (&g_)[K], float &mu_, float &rs_) {
+    float mu = 0.0f, rstd = 0.0f, sc = 1.0f;
+    const float *__restrict__ rsc = p.rscale ? p.rscale : p.rstd;      // always a valid address; unused without rscale
+    auto fetch = [&](long long r_, f4 (&y_)[K], f4 (&z_)[K], f4 (&g_)[K], float &mu_, float &rs_, float &sc_) {
         const long long rc = r_ < p.rows ? r_ : p.rows - 1;
         mu_ = p.mean[rc];
         rs_ = p.rstd[rc];
+        sc_ = rsc[p.rscale ? (unsigned)rc / p.rps : 0u];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const int c = lane + 64 * k, cc = c < nchunk ? c : nchunk - 1;
@@ -119,11 +124,12 @@ __global__ __launch_bounds__(NWV * 64) void normgate_bwd_kernel(const NormGatePa
             g_[k] = ld4(G + rc * D + 4 * cc);
         }
     };
-    if (wave0 < p.rows) fetch(wave0, yv, zv, gv, mu, rstd);
+    if (wave0 < p.rows) fetch(wave0, yv, zv, gv, mu, rstd, sc);
     for (long long r = wave0; r < p.rows; r += nwaves) {
         f4 yn[K], zn[K], gn[K];
-        float mun, rsn;
-        fetch(r + nwaves, yn, zn, gn, mun, rsn);
+        float mun, rsn, scn;
+        fetch(r + nwaves, yn, zn, gn, mun, rsn, scn);
+        const float gsc = p.rscale ? sc : 1.0f;
         f4 nh[K], dn[K];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -138,8 +144,9 @@ __global__ __launch_bounds__(NWV * 64) void normgate_bwd_kernel(const NormGatePa
                     const float n = (yv[k][e] - mu) * rstd;
                     const float v = n * g[k][e] + b[k][e];
                     const float zz = zv[k][e], sg = sigmoidf_fast(zz);
-                    const float dv = gv[k][e] * (zz * sg);
-                    dzv[e] = gv[k][e] * v * (sg * (1.0f + zz * (1.0f - sg)));
+                    const float go = gv[k][e] * gsc;
+                    const float dv = go * (zz * sg);
+                    dzv[e] = go * v * (sg * (1.0f + zz * (1.0f - sg)));
                     ag[k][e] += dv * n;
                     ab[k][e] += dv;
                     const float d = dv * g[k][e];
@@ -166,6 +173,7 @@ __global__ __launch_bounds__(NWV * 64) void normgate_bwd_kernel(const NormGatePa
         for (int k = 0; k < K; ++k) { yv[k] = yn[k]; zv[k] = zn[k]; gv[k] = gn[k]; }
         mu = mun;
         rstd = rsn;
+        sc = scn;
     }
     // per-lane column sums -> per-wave LDS slots -> one global atomic per column and workgroup (at most 256
     // workgroups: thousands of same-address global atomics would serialise at the memory side)
@@ -214,10 +222,24 @@ void launch(bool bwd, const NormGateParams &p, hipStream_t s) {
 
 }  // namespace
 
+static int scale_ok(const float *row_scale, long long rows_per_scale, long long rows, const char *name) {
+    if (row_scale && (rows_per_scale <= 0 || rows_per_scale > 0xffffffffLL || rows > 0xffffffffLL)) {
+        ss2d_set_error("%s: rows_per_scale %lld / rows %lld out of range", name, rows_per_scale, rows); return -3; }
+    return 0;
+}
+
 extern "C" int ss2d_outnorm_gate_fwd(int dtype, const void *y, const void *z, const float *gamma, const float *beta,
                                      void *out, float *mean, float *rstd, long long rows, int D, int ldz, float eps,
                                      void *stream) {
+    return ss2d_outnorm_gate_scaled_fwd(dtype, y, z, gamma, beta, nullptr, 0, out, mean, rstd, rows, D, ldz, eps, stream);
+}
+
+extern "C" int ss2d_outnorm_gate_scaled_fwd(int dtype, const void *y, const void *z, const float *gamma, const float *beta,
+                                            const float *row_scale, long long rows_per_scale, void *out, float *mean,
+                                            float *rstd, long long rows, int D, int ldz, float eps, void *stream) {
     NormGateParams p{};
+    if (scale_ok(row_scale, rows_per_scale, rows, "outnorm_gate_fwd")) return -3;
+    p.rscale = row_scale; p.rps = row_scale ? (unsigned)rows_per_scale : 1u;
     if (!y || !z || !gamma || !beta || !out) { ss2d_set_error("outnorm_gate_fwd: null pointer"); return -2; }
     if ((mean == nullptr) != (rstd == nullptr)) { ss2d_set_error("outnorm_gate_fwd: mean and rstd go together"); return -2; }
     p.y = y; p.z = z; p.gamma = gamma; p.beta = beta; p.out = out; p.mean = mean; p.rstd = rstd;
@@ -234,7 +256,16 @@ extern "C" int ss2d_outnorm_gate_bwd(int dtype, const void *dout, const void *y,
                                      const float *beta, const float *mean, const float *rstd, void *dy, void *dz,
                                      float *dgamma, float *dbeta, long long rows, int D, int ldz, int lddz,
                                      void *stream) {
+    return ss2d_outnorm_gate_scaled_bwd(dtype, dout, y, z, gamma, beta, mean, rstd, nullptr, 0, dy, dz, dgamma, dbeta, rows, D, ldz, lddz, stream);
+}
+
+extern "C" int ss2d_outnorm_gate_scaled_bwd(int dtype, const void *dout, const void *y, const void *z, const float *gamma,
+                                            const float *beta, const float *mean, const float *rstd, const float *row_scale,
+                                            long long rows_per_scale, void *dy, void *dz, float *dgamma, float *dbeta,
+                                            long long rows, int D, int ldz, int lddz, void *stream) {
     NormGateParams p{};
+    if (scale_ok(row_scale, rows_per_scale, rows, "outnorm_gate_bwd")) return -3;
+    p.rscale = row_scale; p.rps = row_scale ? (unsigned)rows_per_scale : 1u;
     if (!dout || !y || !z || !gamma || !beta || !mean || !rstd || !dy || !dz || !dgamma || !dbeta) {
         ss2d_set_error("outnorm_gate_bwd: null pointer"); return -2; }
     p.dout = dout; p.y = y; p.z = z; p.gamma = gamma; p.beta = beta; p.mean = const_cast<float *>(mean);
