@@ -372,6 +372,11 @@ int ss2d_token_gemm(int dtype, const void *A, const void *B, void *C, long long 
  * conditions are those of ss2d_token_gemm. */
 int ss2d_token_gemm_cat(int dtype, const void *A, const void *A2, const void *W, const float *bias, void *C, long long T, int N,
                         int K, int K1, int lda, int lda2, int ldw, int ldc, void *stream);
+/* C (T x N) = R + A (T x K) * W^T with the product rounded to `dtype` before the sum -- bit for bit what the Linear followed
+ * by `x + y` gives: out_proj and the residual connection of a VSSBlock (mamba_sys.py:562, :585) in one pass.  R (T x N, row
+ * stride ldr) in `dtype`; C may be R.  Same alignment rules as ss2d_token_gemm. */
+int ss2d_token_gemm_res(int dtype, const void *A, const void *W, const void *R, void *C, long long T, int N, int K, int lda,
+                        int ldw, int ldr, int ldc, void *stream);
 
 /* Column sums out[j] = sum_r x[r*ldx + j] (fp32) of a (rows, M) matrix in dtype: autograd's bias gradient of the Linears
  * that have a bias (`concat_back_dim`, mamba_sys.py:774-778, applied :835).  Deterministic (per-workgroup partial rows in

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "ss2d_chan_gemm": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i] + [ctypes.c_longlong] * 5 + [_vp]),
     "ss2d_token_gemm": (_i, [_i, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _vp]),
     "ss2d_token_gemm_cat": (_i, [_i, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "ss2d_token_gemm_res": (_i, [_i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _i, _i, _i, _vp]),
     "ss2d_colsum_workspace_floats": (_sz, [_i]),
     "ss2d_colsum": (_i, [_i, _vp, _vp, _vp, ctypes.c_longlong, _i, ctypes.c_longlong, _vp]),
     "ss2d_seg_loss_workspace_floats": (_sz, [_i]),

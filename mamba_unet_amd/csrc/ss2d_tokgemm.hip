@@ -25,10 +25,24 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 struct TgParams {
     const bf16 *A, *A2, *B;     // A2: the token operand of k >= K1 (the skip half of a concatenated input), or A again
     const float *bias;          // (N) fp32, added before the result is rounded; nullable
+    const bf16 *R;              // (T x N, row stride ldr) nullable: C = R + round(A * W^T): the residual sum behind out_proj
     bf16 *C;
     long long T;
-    int N, K, K1, lda, lda2, ldb, ldc, tiles_n;
+    int N, K, K1, lda, lda2, ldb, ldc, ldr, tiles_n;
 };
+
+// a + b over eight bf16 values in four registers, in fp32, rounded once: what `x + y` of two bf16 tensors gives
+__device__ __forceinline__ u32x4 add_bf16x8(u32x4 a, u32x4 b) {
+    typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+    u32x4 o;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const f2 s = f2{__builtin_bit_cast(float, a[i] << 16) + __builtin_bit_cast(float, b[i] << 16),
+                        __builtin_bit_cast(float, a[i] & 0xffff0000u) + __builtin_bit_cast(float, b[i] & 0xffff0000u)};
+        o[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(s, bf16x2v));
+    }
+    return o;
+}
 
 constexpr int GT = 128, GN = 96;                          // tokens, columns per workgroup
 constexpr int BROW_NN = 2 * GN;                           // dX weight chunk [k][96 n]: 192 B = 48 banks, conflict-free for the transposed read
@@ -133,6 +147,17 @@ __global__ __launch_bounds__(256) void tok_gemm_kernel(const TgParams p) {
             }
         }
     }
+    // the residual pieces this thread will add to its six output pieces, requested ahead of the epilogue's two barriers
+    u32x4 rv[6];
+    if (p.R) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int id = j * 256 + tid, row = id / 12, pc = id - row * 12;
+            const long long t = t0 + row;
+            const int n = n0 + pc * 8;
+            rv[j] = *reinterpret_cast<const u32x4 *>(p.R + ((t < p.T && n < p.N) ? t * p.ldr + n : 0));
+        }
+    }
     __syncthreads();
     // accumulator register e of a 32x32 block: row (= column n of the result) 8*(e/4) + 4*(lane/32) + e%4, column (= token)
     // lane%32 -- four consecutive n of one token per register quad: one 8-byte LDS store
@@ -156,7 +181,11 @@ __global__ __launch_bounds__(256) void tok_gemm_kernel(const TgParams p) {
         const int id = j * 256 + tid, row = id / 12, pc = id - row * 12;
         const long long t = t0 + row;
         const int n = n0 + pc * 8;
-        if (t < p.T && n < p.N) *reinterpret_cast<u32x4 *>(p.C + t * p.ldc + n) = *reinterpret_cast<const u32x4 *>(lds + row * CROW + pc * 16);
+        if (t < p.T && n < p.N) {
+            u32x4 v = *reinterpret_cast<const u32x4 *>(lds + row * CROW + pc * 16);
+            if (p.R) v = add_bf16x8(rv[j], v);
+            *reinterpret_cast<u32x4 *>(p.C + t * p.ldc + n) = v;
+        }
     }
 }
 
@@ -173,9 +202,10 @@ __global__ __launch_bounds__(256) void tok_gemm_kernel(const TgParams p) {
 struct TgParamsF {
     const float *A, *A2, *B;
     const float *bias;
+    const float *R;             // residual (see TgParams)
     float *C;
     long long T;
-    int N, K, K1, lda, lda2, ldb, ldc, tiles_n;
+    int N, K, K1, lda, lda2, ldb, ldc, ldr, tiles_n;
 };
 
 constexpr int FK = 32;                                    // k per chunk
@@ -312,23 +342,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         const int id = j * 256 + tid, row = id / 24, pc = id - row * 24;
         const long long t = t0 + row;
         const int n = n0 + pc * 4;
-        if (t < p.T && n < p.N) *reinterpret_cast<u32x4 *>(p.C + t * p.ldc + n) = *reinterpret_cast<const u32x4 *>(lds + row * FCROW + pc * 16);
+        if (t < p.T && n < p.N) {
+            f4 v = *reinterpret_cast<const f4 *>(lds + row * FCROW + pc * 16);
+            if (p.R) v = *reinterpret_cast<const f4 *>(p.R + t * p.ldr + n) + v;
+            *reinterpret_cast<f4 *>(p.C + t * p.ldc + n) = v;
+        }
     }
 }
 
 }  // namespace
 
 namespace {
-int tg_run(const char *name, int dtype, const void *A, const void *A2, const void *B, const float *bias, void *C, long long T, int N, int K,
-           int K1, int lda, int lda2, int ldb, int ldc, int b_k_major, void *stream) {
+int tg_run(const char *name, int dtype, const void *A, const void *A2, const void *B, const float *bias, const void *R, void *C, long long T,
+           int N, int K, int K1, int lda, int lda2, int ldb, int ldr, int ldc, int b_k_major, void *stream) {
     if (dtype != SS2D_DTYPE_BF16 && dtype != SS2D_DTYPE_F32) { ss2d_set_error("%s: unknown dtype %d", name, dtype); return -1; }
     const bool f32 = dtype == SS2D_DTYPE_F32;
     const int q = f32 ? 4 : 8;                                 // elements per 16 bytes
     if (!A || !B || !C || (K1 < K && !A2)) { ss2d_set_error("%s: null required pointer", name); return -2; }
     if (T <= 0 || N <= 0 || K <= 0 || K1 <= 0 || K1 > K || lda < K1 || (K1 < K && lda2 < K - K1) || ldc < N || ldb < (b_k_major ? N : K)) {
         ss2d_set_error("%s: bad size", name); return -3; }
-    if (N % q || K % q || lda % q || ldb % q || ldc % q || (K1 < K && lda2 % q) ||
-        ((((uintptr_t)A | (uintptr_t)(K1 < K ? A2 : A) | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias) & 15) != 0)) {
+    if (R && ldr < N) { ss2d_set_error("%s: bad size", name); return -3; }
+    if (N % q || K % q || lda % q || ldb % q || ldc % q || (K1 < K && lda2 % q) || (R && ldr % q) ||
+        ((((uintptr_t)A | (uintptr_t)(K1 < K ? A2 : A) | (uintptr_t)B | (uintptr_t)C | (uintptr_t)bias | (uintptr_t)R) & 15) != 0)) {
         ss2d_set_error("%s: N, K, the leading dimensions must be multiples of %d and the operands 16-byte aligned", name, q); return -4; }
     const bool k64 = K > 256;
     const int kchunk = f32 ? FK : k64 ? 64 : 32;
@@ -340,14 +375,14 @@ int tg_run(const char *name, int dtype, const void *A, const void *A2, const voi
     if (f32) {
         TgParamsF p;
         p.A = static_cast<const float *>(A); p.A2 = static_cast<const float *>(K1 < K ? A2 : A); p.B = static_cast<const float *>(B);
-        p.bias = bias; p.C = static_cast<float *>(C);
+        p.bias = bias; p.C = static_cast<float *>(C); p.R = static_cast<const float *>(R); p.ldr = ldr;
         p.T = T; p.N = N; p.K = K; p.K1 = K1; p.lda = lda; p.lda2 = K1 < K ? lda2 : lda; p.ldb = ldb; p.ldc = ldc; p.tiles_n = tiles_n;
         if (b_k_major) ss2d_launch((tok_gemm_f32_kernel<true>), dim3((unsigned)nwg), dim3(256), 0, s, p);
         else ss2d_launch((tok_gemm_f32_kernel<false>), dim3((unsigned)nwg), dim3(256), 0, s, p);
     } else {
         TgParams p;
         p.A = static_cast<const bf16 *>(A); p.A2 = static_cast<const bf16 *>(K1 < K ? A2 : A); p.B = static_cast<const bf16 *>(B);
-        p.bias = bias; p.C = static_cast<bf16 *>(C);
+        p.bias = bias; p.C = static_cast<bf16 *>(C); p.R = static_cast<const bf16 *>(R); p.ldr = ldr;
         p.T = T; p.N = N; p.K = K; p.K1 = K1; p.lda = lda; p.lda2 = K1 < K ? lda2 : lda; p.ldb = ldb; p.ldc = ldc; p.tiles_n = tiles_n;
         if (b_k_major) { if (k64) ss2d_launch((tok_gemm_kernel<true, 64>), dim3((unsigned)nwg), dim3(256), 0, s, p); else ss2d_launch((tok_gemm_kernel<true, 32>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
         else { if (k64) ss2d_launch((tok_gemm_kernel<false, 64>), dim3((unsigned)nwg), dim3(256), 0, s, p); else ss2d_launch((tok_gemm_kernel<false, 32>), dim3((unsigned)nwg), dim3(256), 0, s, p); }
@@ -360,12 +395,20 @@ int tg_run(const char *name, int dtype, const void *A, const void *A2, const voi
 
 extern "C" int ss2d_token_gemm(int dtype, const void *A, const void *B, void *C, long long T, int N, int K, int lda, int ldb,
                                int ldc, int b_k_major, void *stream) {
-    return tg_run("token_gemm", dtype, A, nullptr, B, nullptr, C, T, N, K, K, lda, 0, ldb, ldc, b_k_major, stream);
+    return tg_run("token_gemm", dtype, A, nullptr, B, nullptr, nullptr, C, T, N, K, K, lda, 0, ldb, 0, ldc, b_k_major, stream);
+}
+
+// C (T x N) = R + A (T x K) * W^T, the product rounded to the storage type before the sum (what a Linear followed by `x + y`
+// gives): out_proj and the residual connection of a VSSBlock (mamba_sys.py:562, :585) in one pass.  C may be R.
+extern "C" int ss2d_token_gemm_res(int dtype, const void *A, const void *W, const void *R, void *C, long long T, int N, int K,
+                                   int lda, int ldw, int ldr, int ldc, void *stream) {
+    if (!R) { ss2d_set_error("token_gemm_res: null required pointer"); return -2; }
+    return tg_run("token_gemm_res", dtype, A, nullptr, W, nullptr, R, C, T, N, K, K, lda, 0, ldw, ldr, ldc, 0, stream);
 }
 
 // C (T x N) = [A | A2] (T x (K1 + K2)) * W^T + bias: a Linear over a concatenated input without the concatenation, the bias
 // added in fp32 before the result is rounded.  A2 may be null with K1 == K (a plain biased Linear).
 extern "C" int ss2d_token_gemm_cat(int dtype, const void *A, const void *A2, const void *W, const float *bias, void *C, long long T,
                                    int N, int K, int K1, int lda, int lda2, int ldw, int ldc, void *stream) {
-    return tg_run("token_gemm_cat", dtype, A, A2, W, bias, C, T, N, K, K1, lda, lda2, ldw, ldc, 0, stream);
+    return tg_run("token_gemm_cat", dtype, A, A2, W, bias, nullptr, C, T, N, K, K1, lda, lda2, ldw, 0, ldc, 0, stream);
 }

@@ -26,7 +26,7 @@ import torch.utils.checkpoint as checkpoint
 
 from .selective_scan_interface import scan_core_fn, scan_merge_fn, selective_scan_fn
 from .ss2d_ops import (GradHalves, GradSlots, split_halves, apply_linear, apply_norm, apply_norm_skip, block_params, cross_merge, cross_scan, dirs_scatter2, dt_proj, dwconv3x3_silu,
-                       outnorm_gate, scan_params, x_proj)
+                       linear_residual, outnorm_gate, scan_params, x_proj)
 
 
 class DropPath(nn.Module):
@@ -198,7 +198,11 @@ class SS2D(nn.Module):
         return cross_merge(out_y.view(B, K, D, L), H, W, channel_last=True)      # (B, H, W, D)
 
     # ---- mamba_sys.py:552-565
-    def forward(self, x: torch.Tensor, **kwargs):
+    def forward(self, x: torch.Tensor, residual=None, drop_scale=None, **kwargs):
+        """`residual` / `drop_scale` (this build's additions, used by VSSBlock): returns residual + drop_scale[b] * SS2D(x)
+        -- the block's residual connection with its stochastic-depth factor (mamba_sys.py:581-585) -- with the factor
+        applied inside the out_norm + gate kernel (out_proj has no bias: scaling its input equals scaling its output) and
+        the sum inside out_proj's GEMM."""
         D = self.d_inner
         xz = apply_linear(self.in_proj, x)                                         # (B, H, W, 2D)
         fused_gate = self.forward_core == self.forward_corev0 and isinstance(self.out_norm, nn.LayerNorm)
@@ -210,16 +214,25 @@ class SS2D(nn.Module):
             halves = None
             xh, z = torch.split(xz, D, dim=-1)     # views; split's backward is one cat instead of two zero-fills + add
         xc = dwconv3x3_silu(xh, self.conv2d.weight, self.conv2d.bias, channel_last_in=True, holder=halves)
+        fold = (residual is not None and fused_gate and xz.is_cuda and self.dropout is None and self.out_proj.bias is None
+                and not os.environ.get("SS2D_NO_LINEAR_RES"))
         if fused_gate:
             # out_norm, SiLU(z) and the product in one kernel (:452 + :561)
-            y = outnorm_gate(self._scan_core(xc), z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, holder=halves)
+            y = outnorm_gate(self._scan_core(xc), z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, holder=halves,
+                             scale=drop_scale if fold else None)
         else:
             y = self.forward_core(xc)
             y = y * F.silu(z)
+        if fold:
+            return linear_residual(self.out_proj, y, residual)
         out = apply_linear(self.out_proj, y)
         if self.dropout is not None:
             out = self.dropout(out)
-        return out
+        if residual is None:
+            return out
+        if drop_scale is None:
+            return residual + out
+        return _ResidualScaled.apply(residual, out, drop_scale.to(residual.dtype).view((out.shape[0],) + (1,) * (out.dim() - 1)))
 
 
 class _ResidualScaled(torch.autograd.Function):
@@ -256,21 +269,20 @@ class VSSBlock(nn.Module):
 
     def forward(self, input: torch.Tensor):
         ln, input = apply_norm_skip(self.ln_1, input)     # `input` again, with its residual gradient routed through ln_1's backward kernel
-        y = self.self_attention(ln)
         dp = self.drop_path
-        if type(dp) is DropPath and dp.training and dp.drop_prob > 0.0:
-            # residual + stochastic depth in one pass (same Bernoulli draw as DropPath.forward; y*(mask/keep) instead
-            # of (y*mask)/keep): input + y * mask / keep
-            scale = self._dp_scale
-            if scale is not None and not self._dp_keep:
-                self._dp_scale = None                      # one forward only (kept for a checkpointed stage's recomputation)
-            if scale is None or scale.shape[0] != y.shape[0] or scale.device != y.device or scale.dtype != input.dtype:
-                keep = 1.0 - dp.drop_prob
-                mask = y.new_empty((y.shape[0],) + (1,) * (y.dim() - 1)).bernoulli_(keep)
-                # the scale in the residual stream's precision (1 / keep rounded to bf16 first would bias the branch by up to 0.4 %)
-                scale = mask.to(input.dtype).div_(keep)
-            return _ResidualScaled.apply(input, y, scale.view((y.shape[0],) + (1,) * (y.dim() - 1)))
-        return input + dp(y)
+        if type(dp) is DropPath and type(self.self_attention) is SS2D:
+            # residual + stochastic depth inside SS2D's last two kernels: input + SS2D(ln) * mask / keep (the same Bernoulli
+            # draw per sample as timm's DropPath; the factor in fp32)
+            scale = None
+            if dp.training and dp.drop_prob > 0.0:
+                scale = self._dp_scale
+                if scale is not None and not self._dp_keep:
+                    self._dp_scale = None                  # one forward only (kept for a checkpointed stage's recomputation)
+                if scale is None or scale.shape[0] != input.shape[0] or scale.device != input.device:
+                    keep = 1.0 - dp.drop_prob
+                    scale = torch.empty(input.shape[0], device=input.device, dtype=torch.float32).bernoulli_(keep).div_(keep)
+            return self.self_attention(ln, residual=input, drop_scale=scale)
+        return input + dp(self.self_attention(ln))
 
     # per-sample scale mask / keep of this forward, drawn for all blocks of the network at once (VSSM.forward: one Bernoulli
     # launch per step instead of three small launches per block); None: the block draws its own

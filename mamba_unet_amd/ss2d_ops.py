@@ -491,6 +491,61 @@ class _Linear(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearRes(torch.autograd.Function):
+    """res + x W^T for a bias-free Linear (out_proj and the residual connection of a VSSBlock, mamba_sys.py:562, :585) in
+    one pass on the token GEMM (ss2d_token_gemm_res: the product is rounded to the storage type before the sum, bit for bit
+    what the Linear followed by `res + y` gives).  Backward: d res = g as it is, dx and dW as _Linear."""
+
+    @staticmethod
+    def forward(ctx, x, weight, res):
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_dtype("cuda")
+            x, w = x.to(dt), cast_weight(weight, dt)
+        else:
+            w = weight
+        ctx.save_for_backward(x, w)
+        ctx.w_dtype = weight.dtype
+        N, K = w.shape
+        q = 16 // x.element_size()
+        x2, r2 = x.reshape(-1, K), res.reshape(-1, N)
+        ok = (x.dtype in (torch.bfloat16, torch.float32) and w.dtype == x.dtype and res.dtype == x.dtype and x2.is_contiguous() and r2.is_contiguous()
+              and w.is_contiguous() and K % q == 0 and N % q == 0 and (x2.data_ptr() | r2.data_ptr() | w.data_ptr()) % 16 == 0
+              and _token_gemm_pays(x2.shape[0], N, K, x.dtype))
+        if ok:
+            out = torch.empty_like(r2)
+            with _lib.on_device(x.device):
+                rc = _lib.load().ss2d_token_gemm_res(_io(x)[1], _lib.ptr(x2), _lib.ptr(w), _lib.ptr(r2), _lib.ptr(out), x2.shape[0], N, K,
+                                                     K, K, N, N, _stream())
+            _lib.check(rc, "ss2d_token_gemm_res")
+            return out.view(res.shape)
+        with torch.autocast("cuda", enabled=False):
+            return res + torch.nn.functional.linear(x, w).to(res.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        gx = g.to(x.dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = token_gemm(gx, w, True) if _token_gemm_pays(gx.numel() // gx.shape[-1], w.shape[1], w.shape[0], gx.dtype) else None
+            if dx is None:
+                dx = torch.matmul(gx, w)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            own = _own_wgrad_pays(gx.numel() // gx.shape[-1], gx.shape[-1], x.shape[-1], gx.dtype)
+            dw = (linear_wgrad(gx, x) if own else _lib_wgrad(gx, x)).to(ctx.w_dtype)
+        return dx, dw, (g if ctx.needs_input_grad[2] else None)
+
+
+def linear_residual(module: torch.nn.Module, x: torch.Tensor, res: torch.Tensor) -> torch.Tensor:
+    """res + module(x) for a bias-free nn.Linear, as one kernel where the token GEMM applies."""
+    rows = x.numel() // x.shape[-1]
+    if (type(module) is torch.nn.Linear and module.bias is None and x.is_cuda and rows >= 1024 and res.shape[:-1] == x.shape[:-1]
+            and res.shape[-1] == module.out_features and not _os.environ.get("SS2D_NO_WGRAD") and not _os.environ.get("SS2D_NO_LINEAR_RES")):
+        return _LinearRes.apply(x, module.weight, res)
+    return res + apply_linear(module, x)
+
+
 class _ConcatLinear(torch.autograd.Function):
     """y = cat([x, skip], -1) W^T + b without the concatenated tensor (the decoder's skip connection,
     mamba_sys.py:835): W = [W1 | W2], y = x W1^T + b, then y += skip W2^T accumulated in place by the second GEMM.
@@ -568,7 +623,7 @@ def apply_linear(module: torch.nn.Module, x: torch.Tensor) -> torch.Tensor:
 
 class _OutNormGate(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, z, gamma, beta, eps, holder=None):
+    def forward(ctx, y, z, gamma, beta, eps, holder=None, scale=None):
         _need_gpu(y, "outnorm_gate")
         ctx.holder = holder
         D = y.shape[-1]
@@ -592,19 +647,24 @@ class _OutNormGate(torch.autograd.Function):
         out = torch.empty((rows, D), device=y.device, dtype=io)
         mean = torch.empty(rows, device=y.device, dtype=torch.float32)
         rstd = torch.empty_like(mean)
+        rps = 0
+        if scale is not None:      # one factor per sample (leading axis of y): fp32, contiguous
+            if scale.numel() != y.shape[0] or rows % y.shape[0]:
+                raise ValueError("outnorm_gate: `scale` must hold one factor per sample")
+            scale = scale.detach().reshape(-1).float().contiguous()
+            rps = rows // y.shape[0]
         with _lib.on_device(y.device):
-            rc = _lib.load().ss2d_outnorm_gate_fwd(code, _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32), _lib.ptr(b32),
-                                                   _lib.ptr(out), _lib.ptr(mean), _lib.ptr(rstd), rows, D, ldz,
-                                                   float(eps), _stream())
+            rc = _lib.load().ss2d_outnorm_gate_scaled_fwd(code, _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32), _lib.ptr(b32), _lib.ptr(scale), rps,
+                                                          _lib.ptr(out), _lib.ptr(mean), _lib.ptr(rstd), rows, D, ldz, float(eps), _stream())
         _lib.check(rc, "ss2d_outnorm_gate_fwd")
-        ctx.save_for_backward(y2, zs, g32, b32, mean, rstd)
-        ctx.meta = (code, rows, D, ldz, y.shape, z.shape, y.dtype, z.dtype, gamma.dtype, beta.dtype)
+        ctx.save_for_backward(y2, zs, g32, b32, mean, rstd, scale)
+        ctx.meta = (code, rows, D, ldz, y.shape, z.shape, y.dtype, z.dtype, gamma.dtype, beta.dtype, rps)
         return out.view(y.shape)
 
     @staticmethod
     def backward(ctx, dout):
-        y2, zs, g32, b32, mean, rstd = ctx.saved_tensors
-        code, rows, D, ldz, yshape, zshape, ydt, zdt, gdt, bdt = ctx.meta
+        y2, zs, g32, b32, mean, rstd, scale = ctx.saved_tensors
+        code, rows, D, ldz, yshape, zshape, ydt, zdt, gdt, bdt, rps = ctx.meta
         g = dout.reshape(rows, D).to(y2.dtype)
         g = g if g.is_contiguous() else g.contiguous()
         dy = torch.empty_like(y2)
@@ -616,17 +676,19 @@ class _OutNormGate(torch.autograd.Function):
             dz, lddz = torch.empty((rows, D), device=g.device, dtype=y2.dtype), D
         dg, db = _lib.zeros_group(g.device, tuple(g32.shape), tuple(b32.shape))
         with _lib.on_device(g.device):
-            rc = _lib.load().ss2d_outnorm_gate_bwd(code, _lib.ptr(g), _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32),
-                                                   _lib.ptr(b32), _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(dy),
-                                                   _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), rows, D, ldz, lddz, _stream())
+            rc = _lib.load().ss2d_outnorm_gate_scaled_bwd(code, _lib.ptr(g), _lib.ptr(y2), _lib.ptr(zs), _lib.ptr(g32), _lib.ptr(b32),
+                                                          _lib.ptr(mean), _lib.ptr(rstd), _lib.ptr(scale), rps, _lib.ptr(dy),
+                                                          _lib.ptr(dz), _lib.ptr(dg), _lib.ptr(db), rows, D, ldz, lddz, _stream())
         _lib.check(rc, "ss2d_outnorm_gate_bwd")
-        return dy.view(yshape).to(ydt), dz.view(zshape).to(zdt), dg.to(gdt), db.to(bdt), None, None
+        return dy.view(yshape).to(ydt), dz.view(zshape).to(zdt), dg.to(gdt), db.to(bdt), None, None, None
 
 
-def outnorm_gate(y: torch.Tensor, z: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, holder=None) -> torch.Tensor:
+def outnorm_gate(y: torch.Tensor, z: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, holder=None, scale=None) -> torch.Tensor:
     """LayerNorm over the last axis of y (weight, bias, eps) times SiLU(z), fused (mamba_sys.py:452 + :561).
-    z may be a channel slice of a wider tensor (the z half of xz).  Output has y's dtype.  `holder`: see GradHalves."""
-    return _OutNormGate.apply(y, z, weight, bias, eps, holder)
+    z may be a channel slice of a wider tensor (the z half of xz).  Output has y's dtype.  `holder`: see GradHalves.
+    `scale` (one factor per sample, not differentiated): multiplied into the output -- the block's stochastic-depth factor,
+    applied in front of the bias-free out_proj (mamba_sys.py:581-585)."""
+    return _OutNormGate.apply(y, z, weight, bias, eps, holder, scale)
 
 
 class _LayerNorm(torch.autograd.Function):

@@ -165,7 +165,7 @@ class VSSM(nn.Module):
         if getattr(self, "_dp_key", None) != key:
             self._dp_key, self._dp_keep_prob = key, torch.tensor([1.0 - q for q in key[1]], device=x.device).view(-1, 1)
         keep = self._dp_keep_prob
-        scale = torch.bernoulli(keep.expand(len(live), x.shape[0])).div_(keep).to(x.dtype)
+        scale = torch.bernoulli(keep.expand(len(live), x.shape[0])).div_(keep)       # fp32: applied inside the out_norm + gate kernel
         for i, (blk, ckpt) in enumerate(live):
             blk._dp_scale, blk._dp_keep = scale[i], bool(ckpt)
 

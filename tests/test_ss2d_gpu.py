@@ -223,6 +223,62 @@ def test_outnorm_gate_fused(rows_shape, D, dtype):
     assert rel_l2(wd.grad.cpu(), wr.grad) < ptol and rel_l2(bd.grad.cpu(), br.grad) < ptol
 
 
+@pytest.mark.parametrize("rows_shape,D,dtype", [((3, 5, 7), 192, torch.float32), ((2, 14, 14), 768, torch.float32), ((4, 9, 9), 384, torch.bfloat16)])
+def test_outnorm_gate_with_per_sample_scale(rows_shape, D, dtype):
+    """out = LayerNorm(y) * SiLU(z) * scale[b] (the block's stochastic-depth factor mask / keep, mamba_sys.py:581-585, applied in
+    front of the bias-free out_proj): forward and all gradients against torch fp64; a dropped sample (factor 0) gets no gradient."""
+    from mamba_unet_amd import outnorm_gate
+    gen = torch.Generator().manual_seed(D + 11)
+    B = rows_shape[0]
+    y = (torch.randn(*rows_shape, D, generator=gen) * 2 + 0.3).to(dtype)
+    xz = torch.randn(*rows_shape, 2 * D, generator=gen).to(dtype)
+    w, b = torch.rand(D, generator=gen) + 0.5, torch.randn(D, generator=gen) * 0.1
+    go = torch.randn(*rows_shape, D, generator=gen).to(dtype)
+    scale = torch.tensor([0.0] + [1.0 / 0.9] * (B - 1))
+    yr, xzr = y.double().requires_grad_(True), xz.double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(yr, (D,), wr, br, 1e-5) * torch.nn.functional.silu(xzr[..., D:]) * scale.double().view(B, 1, 1, 1)
+    ref.backward(go.double())
+    yd, xzd = y.cuda().requires_grad_(True), xz.cuda().requires_grad_(True)
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    out = outnorm_gate(yd, xzd[..., D:], wd, bd, 1e-5, scale=scale.cuda())
+    out.backward(go.cuda())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(out.detach().float().cpu(), ref.detach()) < tol and not out[0].any()
+    assert rel_l2(yd.grad.float().cpu(), yr.grad) < tol and not yd.grad[0].any()
+    assert rel_l2(xzd.grad[..., D:].float().cpu(), xzr.grad[..., D:]) < tol
+    ptol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert rel_l2(wd.grad.cpu(), wr.grad) < ptol and rel_l2(bd.grad.cpu(), br.grad) < ptol
+
+
+@pytest.mark.parametrize("T_shape,N,K,dtype", [((2, 56, 56), 96, 192, torch.bfloat16), ((2, 56, 56), 96, 192, torch.float32),
+                                                ((24, 28, 28), 192, 384, torch.bfloat16), ((3, 19, 23), 104, 72, torch.bfloat16),
+                                                ((24, 56, 56), 96, 192, torch.float32)])
+def test_linear_residual_equals_linear_then_add(T_shape, N, K, dtype):
+    """res + x W^T on the token GEMM (ss2d_token_gemm_res: out_proj + the residual connection, mamba_sys.py:562, :585): the
+    forward bit for bit what `linear` followed by `res + y` gives (the product is rounded before the sum), the gradients
+    those of the two-op form."""
+    from mamba_unet_amd.ss2d_ops import linear, linear_residual
+    gen = torch.Generator().manual_seed(N + K)
+    lin = torch.nn.Linear(K, N, bias=False).cuda().to(dtype)
+    x = torch.randn(*T_shape, K, generator=gen).cuda().to(dtype)
+    res = torch.randn(*T_shape, N, generator=gen).cuda().to(dtype)
+    g = torch.randn(*T_shape, N, generator=gen).cuda().to(dtype)
+    outs = []
+    for fused in (True, False):
+        xi, ri = x.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        lin.weight.grad = None
+        o = linear_residual(lin, xi, ri) if fused else ri + linear(xi, lin.weight, None)
+        o.backward(g)
+        outs.append((o.detach(), xi.grad, ri.grad, lin.weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
+    # atomically accumulated in fp32 (order-dependent last bit), then rounded to the weight's dtype
+    assert rel_l2(outs[0][3].float().cpu(), outs[1][3].float().cpu()) < (1e-6 if dtype == torch.float32 else 1e-3)
+    ref = res.double() + x.double() @ lin.weight.detach().double().t()
+    assert rel_l2(outs[0][0].float().cpu(), ref.cpu()) < (1e-5 if dtype == torch.float32 else 1e-2)
+
+
 @pytest.mark.parametrize("rows_shape,D,dtype,autocast", [((2, 56, 56), 96, torch.float32, False), ((1, 14, 14), 768, torch.float32, False),
                                                           ((3, 7, 7), 1536, torch.float32, False), ((777,), 20, torch.float32, False),
                                                           ((2, 28, 28), 384, torch.bfloat16, False), ((2, 28, 28), 192, torch.float32, True)])
