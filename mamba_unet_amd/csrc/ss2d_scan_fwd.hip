@@ -78,25 +78,33 @@ __device__ unsigned long long *g_fwd_probe;
 // DT: delta is not read but computed in the kernel from the rank-R rows of the x_proj output (mamba_sys.py:417-420:
 //     delta[d, l] = sum_r dt_w[d, r] * dts[r, l]): the chunk's (R, 128) tile is staged in LDS beside B / C, the 16
 //     weight rows of the workgroup's channels once; 8R FMAs per lane and chunk instead of a (B, K*D, L) tensor.
-template <int NW, bool HAS_Z, bool VEC4, bool FULL, typename IO, bool DIRS, bool DT = false>
+// PACK: sequences of at most 64 positions (one chunk: the 7 x 7 and 8 x 8 stages), TWO channels per DPP row -- lanes 0-7 of
+//     a row walk one channel, lanes 8-15 the next (a wave advances 8 channels): the row scan is cut between lanes 7 and 8
+//     (lane 8's aggregate decay is zeroed going in, its incoming state coming out).  With one channel per row 9 of 16 lanes
+//     idle at L = 56 and the kernel costs what it costs at L = 128.
+template <int NW, bool HAS_Z, bool VEC4, bool FULL, typename IO, bool DIRS, bool DT = false, bool PACK = false>
 __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const ScanFwdParams p) {
+    static_assert(!PACK || (VEC4 && FULL && !HAS_Z && !DT), "the packed form exists for the SS2D call pattern only");
+    constexpr int CPR = PACK ? 2 : 1;      // channels per DPP row
     // [buffer][B|C][(pair*4 + quarter)*16 + seg] ; one f4 = (n,t),(n+1,t),(n,t+1),(n+1,t+1)
     __shared__ f4 tile[2][2][NP * 4 * 16];
     __shared__ __align__(16) float dtile[DT ? 2 : 1][DT ? MAXR : 1][DT ? CHUNK : 4];
     __shared__ float wtile[DT ? NW * 4 : 1][DT ? MAXR : 1];
-    __shared__ f2 A2s[NW * 4][NP];
+    __shared__ f2 A2s[NW * 4 * CPR][NP];
 #ifdef SS2D_FWD_PROBE
     unsigned pacc[FWD_NPROBE] = {};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
     const unsigned long long tstart = tprev, rstart = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, seg = lane & 15;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, seg = lane & 15;
+    // PACK: `row` counts channel slots of the wave (0-7), `sg` the lane's segment inside its channel (0-7)
+    const int row = PACK ? (lane >> 4) * 2 + (seg >> 3) : lane >> 4, sg = PACK ? seg & 7 : seg;
     int blk = xcd_remap(blockIdx.x, p.nwg);
     const int cb = blk % p.wgs_per_group;
     blk /= p.wgs_per_group;
     const int g = blk % p.G, b = blk / p.G;
-    const int c_in_g = cb * (NW * 4) + wave * 4 + row;
+    const int c_in_g = cb * (NW * 4 * CPR) + wave * (4 * CPR) + row;
     const bool row_ok = c_in_g < p.dpg;
     const int c = g * p.dpg + (row_ok ? c_in_g : 0);
     const int L = p.L, N = FULL ? 16 : p.N;
@@ -117,8 +125,8 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
     // operations path dependent; it then waits for vmcnt(0) before the prefetched tile is used -- that is, for the
     // stores issued a moment ago -- which the probes showed as 11 % of a wave's time.)
     constexpr bool FAST = VEC4 && FULL && !HAS_Z;
-    const int c0_in_g = cb * (NW * 4) + __builtin_amdgcn_readfirstlane(wave) * 4;
-    const int nrow = __builtin_amdgcn_readfirstlane(p.dpg - c0_in_g < 0 ? 0 : (p.dpg - c0_in_g > 4 ? 4 : p.dpg - c0_in_g));
+    const int c0_in_g = cb * (NW * 4 * CPR) + __builtin_amdgcn_readfirstlane(wave) * (4 * CPR);
+    const int nrow = __builtin_amdgcn_readfirstlane(p.dpg - c0_in_g < 0 ? 0 : (p.dpg - c0_in_g > 4 * CPR ? 4 * CPR : p.dpg - c0_in_g));
     const size_t wrow0 = (size_t)b * p.dim + (size_t)g * p.dpg + c0_in_g;
     const __amdgpu_buffer_rsrc_t out_rs = make_rsrc(static_cast<IO *>(p.out) + wrow0 * L, FAST ? (unsigned)(nrow * L * (int)sizeof(IO)) : 0u);
     const __amdgpu_buffer_rsrc_t ck_rs = make_rsrc(p.ckpt ? p.ckpt + wrow0 * p.nchunks * 16 : nullptr,
@@ -128,10 +136,10 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
     // A * log2(e) of the row's 16 states lives in LDS (one ds_read_b64 per pair and chunk): 16 registers that pay for the
     // B/C tile prefetch below without giving up the third wave per SIMD
     f2 carry[NP];
-    if (seg < NP) {
-        const float a0 = (2 * seg < N) ? p.A[(size_t)c * N + 2 * seg] : 0.0f;
-        const float a1 = (2 * seg + 1 < N) ? p.A[(size_t)c * N + 2 * seg + 1] : 0.0f;
-        A2s[wave * 4 + row][seg] = f2{a0, a1} * SS2D_LOG2E;           // visible behind the first barrier
+    if (sg < NP) {
+        const float a0 = (2 * sg < N) ? p.A[(size_t)c * N + 2 * sg] : 0.0f;
+        const float a1 = (2 * sg + 1 < N) ? p.A[(size_t)c * N + 2 * sg + 1] : 0.0f;
+        A2s[wave * (4 * CPR) + row][sg] = f2{a0, a1} * SS2D_LOG2E;           // visible behind the first barrier
     }
 #pragma unroll
     for (int np = 0; np < NP; ++np) carry[np] = f2{0.0f, 0.0f};
@@ -155,8 +163,8 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
             load8d<VEC4, DIRS>(rowp, q0, L, row_ok, rev, v);
         }
     };
-    fetch_row(urow, seg * T, uv);
-    if (!DT) fetch_row(drow, seg * T, dn);
+    fetch_row(urow, sg * T, uv);
+    if (!DT) fetch_row(drow, sg * T, dn);
 
     // B/C tile item `it` = (state pair, 4 positions): two rows of each matrix
     auto tile_fetch = [&](int base_, int it, f4 (&lo)[2], f4 (&hi)[2]) {
@@ -259,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
             }
         }
         // ---- this lane's 8 positions of u / delta
-        const int p0 = base + seg * T;
+        const int p0 = base + sg * T;
         float dt[T], du[T];
         float S = 0.0f;
         f2 y2[T];
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
         }
 
         if (FAST) {   // state entering this chunk, for the backward: lane 0 of every row, 64 bytes
-            const unsigned co = seg == 0 ? (unsigned)((row * p.nchunks + chunk) * 64) : OOB;
+            const unsigned co = sg == 0 ? (unsigned)((row * p.nchunks + chunk) * 64) : OOB;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f4{carry[2 * q].x, carry[2 * q].y, carry[2 * q + 1].x, carry[2 * q + 1].y}),
@@ -335,10 +343,10 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
         for (int np = 0; np < NP; ++np) {
             if (FULL || 2 * np < N) {  // wave-uniform
                 f2 a[T], bb[T];
-                const f2 A2np = A2s[wave * 4 + row][np];
+                const f2 A2np = A2s[wave * (4 * CPR) + row][np];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f4 Bq = tile[buf][0][(np * 4 + j) * 16 + (seg ^ ((j >> 1) * 4))];
+                    const f4 Bq = tile[buf][0][(np * 4 + j) * 16 + (sg ^ ((j >> 1) * 4))];
                     bb[2 * j] = splat2(du[2 * j]) * f2{Bq.x, Bq.y};
                     bb[2 * j + 1] = splat2(du[2 * j + 1]) * f2{Bq.z, Bq.w};
                 }
@@ -350,14 +358,16 @@ __global__ __launch_bounds__(NW * 64) SS2D_FWD_WAVES void scan_fwd_kernel(const 
                 for (int t = 0; t < T; ++t) h = fma2(a[t], h, bb[t]);
                 f2 at = exp2_2(splat2(S) * A2np);
                 float hx = h.x, hy = h.y, ax = at.x, ay = at.y;
+                if (PACK) { ax = seg == 8 ? 0.0f : ax; ay = seg == 8 ? 0.0f : ay; }   // nothing crosses from lane 7 into lane 8
                 row_scan_pair(hx, hy, ax, ay);
                 // state entering this lane = inclusive result of the lane to the left (carry for lane 0)
                 h.x = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(carry[np].x, hx);
                 h.y = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(carry[np].y, hy);
+                if (PACK) { h.x = seg == 8 ? 0.0f : h.x; h.y = seg == 8 ? 0.0f : h.y; }   // the second channel starts from state 0 (one chunk)
                 // pass 2: true states, fused with the C contraction
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const f4 Cq = tile[buf][1][(np * 4 + j) * 16 + (seg ^ ((j >> 1) * 4))];
+                    const f4 Cq = tile[buf][1][(np * 4 + j) * 16 + (sg ^ ((j >> 1) * 4))];
                     h = fma2(a[2 * j], h, bb[2 * j]);
                     y2[2 * j] = fma2(f2{Cq.x, Cq.y}, h, y2[2 * j]);
                     h = fma2(a[2 * j + 1], h, bb[2 * j + 1]);
@@ -440,6 +450,13 @@ int launch_fwd_dt(int nw, const ScanFwdParams &p, hipStream_t s) {
     return ss2d_take_launch_rc();
 }
 
+// two channels per DPP row (L <= 64, one chunk): 16 states, no z, 4-element rows, four waves = 32 channels per workgroup
+template <typename IO, bool DIRS>
+int launch_fwd_pack(const ScanFwdParams &p, hipStream_t s) {
+    ss2d_launch((scan_fwd_kernel<4, false, true, true, IO, DIRS, false, true>), dim3(p.nwg), dim3(256), 0, s, p);
+    return ss2d_take_launch_rc();
+}
+
 template <typename IO, bool DIRS>
 int launch_fwd_nw(int nw, const ScanFwdParams &p, bool has_z, bool vec4, hipStream_t s) {
     return nw == 4 ? launch_fwd<4, IO, DIRS>(p, has_z, vec4, s) : nw == 2 ? launch_fwd<2, IO, DIRS>(p, has_z, vec4, s)
@@ -518,15 +535,25 @@ static int scan_fwd_impl(int dtype, const void *u, const void *delta, const floa
     int nw = p.dpg >= 16 ? 4 : (p.dpg >= 8 ? 2 : 1);
     static const int env_nw = (int)ss2d_env_ll("SS2D_FWD_NW", 0);   // tuning knob, read once
     if (env_nw == 1 || env_nw == 2 || env_nw == 4) nw = env_nw;
-    p.wgs_per_group = (p.dpg + nw * 4 - 1) / (nw * 4);
-    const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
-    if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_fwd: grid too large"); return -6; }
-    p.nwg = (int)nwg;
     const uintptr_t amask = dtype == SS2D_DTYPE_BF16 ? 7 : 15;  // 4 elements
     const bool vec4 = (L % 4 == 0) && (bc_bg_stride % 4 == 0) &&
                       ((((uintptr_t)u | (uintptr_t)delta | (uintptr_t)B | (uintptr_t)C | (uintptr_t)out | (uintptr_t)z) & amask) == 0);
+    // sequences that fit half a DPP row (the 7 x 7 / 8 x 8 stages): two channels per row, 32 per workgroup
+    static const bool env_nopack = getenv("SS2D_FWD_NO_PACK") != nullptr;      // A/B switch, read once
+    const bool pack = !env_nopack && !dt_w && !z && !last_state && dstate == 16 && vec4 && L <= CHUNK / 2 && nw == 4 && p.dpg >= 32;
+    const int cpw = pack ? 32 : nw * 4;                          // channels per workgroup
+    p.wgs_per_group = (p.dpg + cpw - 1) / cpw;
+    const long long nwg = (long long)batch * ngroups * p.wgs_per_group;
+    if (nwg > 0x7fffffffLL) { ss2d_set_error("selective_scan_fwd: grid too large"); return -6; }
+    p.nwg = (int)nwg;
     hipStream_t s = (hipStream_t)stream;
     const bool dirs = rev_mask != 0 || u_groups != ngroups || bc_bg_stride != bc_dense;
+    if (pack) {
+        const int rc = dtype == SS2D_DTYPE_BF16 ? (dirs ? launch_fwd_pack<bf16, true>(p, s) : launch_fwd_pack<bf16, false>(p, s))
+                                                : (dirs ? launch_fwd_pack<float, true>(p, s) : launch_fwd_pack<float, false>(p, s));
+        if (rc) ss2d_set_error("selective_scan_fwd: launch failed: %s", hipGetErrorString((hipError_t)rc));
+        return rc;
+    }
     if (dt_w) {
         if (!vec4) { ss2d_set_error("selective_scan_core_fwd: u, x_dbl and out must be aligned to 4 elements"); return -7; }
         const int rc = dtype == SS2D_DTYPE_BF16 ? launch_fwd_dt<bf16>(nw, p, s) : launch_fwd_dt<float>(nw, p, s);

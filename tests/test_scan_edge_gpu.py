@@ -61,6 +61,35 @@ def test_scan_fwd_bwd_edge_shapes_against_c_oracle(batch, dim, L, N, G):
         assert rel_max(g[src], gr[k]) < MAX_TOL, (k, rel_max(g[src], gr[k]))
 
 
+@pytest.mark.parametrize("batch,dim,L,N,G", [
+    (2, 6144, 56, 16, 4),     # the 7 x 7 stage with its rows padded to 56 (SS2D._scan_core_dirs)
+    (3, 160, 64, 16, 4),      # 40 channels per group: a full workgroup of 32 and a ragged one; exactly half a chunk
+    (1, 128, 8, 16, 4),       # one lane per channel
+    (2, 256, 28, 16, 2),
+    (2, 132, 60, 16, 4),      # 33 channels per group: a workgroup with a single channel
+    (1, 64, 68, 16, 2),       # just past the packed form's limit: one channel per row again
+])
+def test_short_sequences_two_channels_per_row_against_c_oracle(batch, dim, L, N, G):
+    """Sequences of at most 64 positions run two channels per DPP row in the forward (scan_fwd_kernel<..., PACK>: the row scan is
+    cut between lanes 7 and 8); the call without last_state is the one SS2D issues.  Forward and all gradients against the
+    plain-C oracle."""
+    from mamba_unet_amd import selective_scan_fn
+    from oracle import c_ref
+    from oracle.ss2d_ref import make_scan_inputs
+    inp = make_scan_inputs(batch, dim, L, dstate=N, ngroups=G, seed=dim + L, integer_A=False)
+    dout = torch.randn(batch, dim, L, generator=torch.Generator().manual_seed(2))
+    leaves = {k: v.cuda().requires_grad_(True) for k, v in inp.items()}
+    y = selective_scan_fn(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"], None, leaves["delta_bias"], True)
+    y.backward(dout.cuda())
+    n = {k: v.numpy() for k, v in inp.items()}
+    yr = c_ref.scan_fwd(n["u"], n["delta"], n["A"], n["B"], n["C"], n["D"], None, n["delta_bias"], True)
+    gr = c_ref.scan_bwd(n["u"], n["delta"], n["A"], n["B"], n["C"], n["D"], None, n["delta_bias"], dout.numpy(), True)
+    assert rel_l2(y.detach().cpu(), yr) < L2_TOL and rel_max(y.detach().cpu(), yr) < MAX_TOL
+    names = {"du": "u", "ddelta": "delta", "dA": "A", "dB": "B", "dC": "C", "dD": "D", "ddelta_bias": "delta_bias"}
+    for k, src in names.items():
+        assert rel_l2(leaves[src].grad.cpu(), gr[k]) < L2_TOL, (k, rel_l2(leaves[src].grad.cpu(), gr[k]))
+
+
 def test_scan_rejects_bad_arguments():
     from mamba_unet_amd import selective_scan_fn
     u = torch.randn(1, 8, 16, device="cuda")

@@ -106,14 +106,15 @@ def test_ss2d_module_matches_reference_golden(name):
     m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
     m = m.cuda()
     x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    # gates at ~10x the measured errors (tools/parity_margins.py: outputs <= 4.2e-7, dx <= 4.0e-7, parameter gradients <= 8.1e-7)
     core = m.forward_corev0(torch.from_numpy(g["core_in"]).cuda())
-    assert rel_max(core.detach().cpu(), g["core_out"]) < 2e-5
+    assert rel_max(core.detach().cpu(), g["core_out"]) < 5e-6
     y = m(x)
-    assert rel_max(y.detach().cpu(), g["y"]) < 2e-5 and rel_l2(y.detach().cpu(), g["y"]) < 1e-5
+    assert rel_max(y.detach().cpu(), g["y"]) < 5e-6 and rel_l2(y.detach().cpu(), g["y"]) < 5e-6
     (y * torch.from_numpy(g["g"]).cuda()).sum().backward()
-    assert rel_l2(x.grad.cpu(), g["dx"]) < 2e-5
+    assert rel_l2(x.grad.cpu(), g["dx"]) < 5e-6
     for k, p in m.named_parameters():
-        assert rel_l2(p.grad.cpu(), g["grad." + k]) < 5e-5, (k, rel_l2(p.grad.cpu(), g["grad." + k]))
+        assert rel_l2(p.grad.cpu(), g["grad." + k]) < 1e-5, (k, rel_l2(p.grad.cpu(), g["grad." + k]))
 
 
 def test_vssm_small_logits_match_reference_golden():
@@ -124,7 +125,7 @@ def test_vssm_small_logits_match_reference_golden():
     m = m.cuda().eval()
     with torch.no_grad():
         y = m(torch.from_numpy(g["x"]).cuda())
-    assert rel_max(y.cpu(), g["logits"]) < 5e-5 and rel_l2(y.cpu(), g["logits"]) < 2e-5
+    assert rel_max(y.cpu(), g["logits"]) < 1.5e-5 and rel_l2(y.cpu(), g["logits"]) < 1e-5      # measured 1.1e-6 / 5.8e-7
 
 
 def test_config0_vssm_tiny_224_logits_match_reference_golden():
@@ -138,7 +139,7 @@ def test_config0_vssm_tiny_224_logits_match_reference_golden():
     with torch.no_grad():
         y = net(torch.from_numpy(g["x"]).cuda())          # 1 channel in: MambaUnet repeats it to 3 (vision_mamba.py:43-44)
     assert y.shape == (1, 4, 224, 224)
-    assert rel_l2(y.cpu(), g["logits"]) < 2e-5 and rel_max(y.cpu(), g["logits"]) < 1e-4
+    assert rel_l2(y.cpu(), g["logits"]) < 1e-5 and rel_max(y.cpu(), g["logits"]) < 1.5e-5      # measured 1.1e-6 / 1.4e-6
 
 
 def test_mambaunet_train_step_runs():
