@@ -317,10 +317,11 @@ __device__ __forceinline__ void buf_store2m(__amdgpu_buffer_rsrc_t rs, int pos, 
 // long, and positions past the row end are pushed out of range explicitly.  The block must be shorter than 2^31 bytes.
 constexpr int SS2D_BUF_OOR = 0x7ffffff0;   // + any soff < 2^31 stays a 32-bit offset beyond every such block
 template <bool VEC, typename IO>
-__device__ __forceinline__ f2 buf_load2s(__amdgpu_buffer_rsrc_t rs, int pos, int L, bool rev, int soff) {
+__device__ __forceinline__ f2 buf_load2s(__amdgpu_buffer_rsrc_t rs, int pos, int L, bool rev, int soff, int vextra = 0) {
+    // vextra (VEC only): a per-lane byte offset on top of the scalar one (lanes of one wave on different rows)
     constexpr bool F32 = sizeof(IO) == 4;
     if (VEC) {
-        const int off = pos < L ? (rev ? L - 2 - pos : pos) * (int)sizeof(IO) : SS2D_BUF_OOR;
+        const int off = pos < L ? (rev ? L - 2 - pos : pos) * (int)sizeof(IO) + vextra : SS2D_BUF_OOR;
         f2 t;
         if (F32) t = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, soff, 0));
         else t = bf16pair_to_f2(__builtin_amdgcn_raw_buffer_load_b32(rs, off, soff, 0));
@@ -336,10 +337,10 @@ __device__ __forceinline__ f2 buf_load2s(__amdgpu_buffer_rsrc_t rs, int pos, int
     return r;
 }
 template <bool VEC, typename IO>
-__device__ __forceinline__ void buf_store2s(__amdgpu_buffer_rsrc_t rs, int pos, int L, bool rev, f2 v, int soff) {
+__device__ __forceinline__ void buf_store2s(__amdgpu_buffer_rsrc_t rs, int pos, int L, bool rev, f2 v, int soff, int vextra = 0) {
     constexpr bool F32 = sizeof(IO) == 4;
     if (VEC) {
-        const int off = pos < L ? (rev ? L - 2 - pos : pos) * (int)sizeof(IO) : SS2D_BUF_OOR;
+        const int off = pos < L ? (rev ? L - 2 - pos : pos) * (int)sizeof(IO) + vextra : SS2D_BUF_OOR;
         const f2 w = rev ? f2{v.y, v.x} : v;
         if (F32) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, w), rs, off, soff, 0);
         else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, __builtin_convertvector(w, bf16x2)), rs, off, soff, 0);

@@ -98,6 +98,21 @@ __device__ __forceinline__ void row_sum6_to_lane15(float &a, float &b, float &c,
 #undef SS2D_ASTEP6
 }
 
+// the same over the two halves of a row: lane 7 gets the sum of lanes 0-7, lane 15 that of lanes 8-15 (the packed
+// backward: two channels per row)
+__device__ __forceinline__ void row_sum6_to_lanes7_15(float &a, float &b, float &c, float &d, float &e, float &f) {
+#define SS2D_ASTEP6(n)                                                                             \
+    "v_add_f32_dpp %0, %0, %0 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %1, %1, %1 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %2, %2, %2 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %3, %3, %3 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %4, %4, %4 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"          \
+    "v_add_f32_dpp %5, %5, %5 row_shr:" #n " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+    asm volatile("s_nop 1\n\t" SS2D_ASTEP6(1) SS2D_ASTEP6(2) SS2D_ASTEP6(4)
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+#undef SS2D_ASTEP6
+}
+
 // Sum four per-lane values over the 4 DPP rows of the wave: on return row r of the result holds the
 // total (over rows) of x_r.  v_permlane16_swap exchanges the odd rows of its first operand with the
 // even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the

@@ -60,8 +60,14 @@ __device__ unsigned long long *g_sr_probe;
 // DTR > 0: the fused-delta form (ss2d_selective_scan_core_bwd): p.delta points at the rank-DTR dts rows of the x_proj output
 // and delta[c, l] = sum_r dtw[c, r] * dts[r, l] is recomputed for the lane's two positions (2*DTR FMAs per channel-chunk);
 // the dts values of a chunk stay in 2*DTR registers, the weight row of a channel arrives through scalar loads.
-template <bool VEC, typename IO, bool DIRS, bool WS, int DTR = 0>
+// PACK: sequences of at most 64 positions (one chunk: the 7 x 7 / 8 x 8 stages).  A wave works on TWO channels at a time: lanes
+// 0-7 of every row hold the 64 positions of channel 2k, lanes 8-15 those of channel 2k + 1.  The row scans are cut between
+// lanes 7 and 8 (the aggregate decay of the lane on the far side is zeroed going in, its incoming value coming out), the
+// per-channel row sums stop at 8 lanes, and before the flush lane s adds lane s + 8's dB / dC sums (the same positions).
+// With one channel per wave 9 of 16 lanes idle at L = 56 and a call costs what it costs at L = 128.
+template <bool VEC, typename IO, bool DIRS, bool WS, int DTR = 0, bool PACK = false>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void scan_bwd_sr_kernel(const ScanBwdParams p) {
+    static_assert(!PACK || (VEC && DTR == 0), "the packed form: 4-element rows, materialised delta");
     extern __shared__ __align__(16) float smem[];
 #ifdef SS2D_SR_PROBE
     unsigned pacc[SR_NPROBE] = {};
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     float *slots = smem;                                        // [NW][SLOT]; slot 0 doubles as the B/C tile
     f4 *tile = reinterpret_cast<f4 *>(smem);                   // [B|C][pair][item pair][seg] f4, as in ss2d_scan_fwd.hip
     const int tid = threadIdx.x, lane = tid & 63, row = lane >> 4, seg = lane & 15;
+    const int half = PACK ? seg >> 3 : 0, sg = PACK ? seg & 7 : seg;     // PACK: which of the wave's two channels, segment inside it
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float *st = smem + NW * SLOT + wave * STG;
     float *recs = smem + NW * SLOT + NW * STG;                                  // one record per channel of the part
@@ -92,7 +99,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         // The n <= NW * CW_MAX channels of the part are dealt to the waves one at a time inside every chunk (wave w starts
         // with channel w, then takes tickets from an LDS counter): the two waves of a SIMD do not advance at the same
         // rate, and with a fixed split the barrier in front of the flush waited 13 % of the kernel time for the slower one.
-        const int kfirst = wave < n ? wave : 0;                    // a wave without a channel still prefetches a valid row
+        const int nu_ = PACK ? (n + 1) >> 1 : n;                   // work units of the part: channels, or pairs of channels
+        const int kfirst = wave < nu_ ? wave : 0;                  // a wave without a channel still prefetches a valid row
         const size_t r0 = (size_t)part_lo;                          // (batch, channel) row of the part's first channel
         const int cin0 = (int)(r0 - (size_t)bg * p.dpg);
         const int cdim0 = g * p.dpg + cin0;
@@ -110,7 +118,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const bool has_bias = p.bias != nullptr, has_D = p.D != nullptr;
         const unsigned rowbytes = (unsigned)L * sizeof(IO);
 
-        for (int i = tid; i < n * REC; i += NW * 64) recs[i] = 0.0f;   // visible to all waves behind the first barrier of the chunk loop
+        for (int i = tid; i < (PACK ? 2 * nu_ : n) * REC; i += NW * 64) recs[i] = 0.0f;   // visible to all waves behind the first barrier of the chunk loop
 
         // Everything that comes from memory is requested one step ahead and never under a branch (a load under a
         // branch makes the compiler wait for every outstanding load at the join):
@@ -157,12 +165,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const __amdgpu_buffer_rsrc_t rsCk = make_rsrc(p.ckpt + r0 * (size_t)nchunks * 16, 64u * n * nchunks);
         const __amdgpu_buffer_rsrc_t rsBi = make_rsrc(biasp + cdim0, 4u * n);
         const __amdgpu_buffer_rsrc_t rsDp = make_rsrc(Dp + cdim0, 4u * n);
+        // PACK: unit k_ = channels 2 k_ (+ half); the lane's row is chosen by a vector offset on top of the scalar one, and a
+        // channel past the part (odd n) is sent out of range: it reads zeros and drops its stores
+        const bool odd_out = PACK && (n & 1) && half;              // this half has no channel in the part's last unit
         auto input_load = [&](int k_, int chunk_) {
-            const int ps_ = chunk_ * CHUNK + 8 * seg + 2 * row;
-            const int so_ = k_ * (int)rowbytes;
-            nu = buf_load2s<VEC, IO>(rsU, ps_, L, rev, so_);
-            if (DTR == 0) nd = buf_load2s<VEC, IO>(rsDl, ps_, L, rev, so_);
-            ny = buf_load2s<VEC, IO>(rsY, ps_, L, rev, so_);
+            const int ps_ = chunk_ * CHUNK + 8 * sg + 2 * row;
+            const int so_ = (PACK ? 2 * k_ : k_) * (int)rowbytes;
+            const int ve_ = PACK ? ((odd_out && k_ == nu_ - 1) ? SS2D_BUF_OOR : half * (int)rowbytes) : 0;
+            nu = buf_load2s<VEC, IO>(rsU, ps_, L, rev, so_, ve_);
+            if (DTR == 0) nd = buf_load2s<VEC, IO>(rsDl, ps_, L, rev, so_, ve_);
+            ny = buf_load2s<VEC, IO>(rsY, ps_, L, rev, so_, ve_);
             if (DTR > 0) {
                 const cfp wp = (cfp)(uintptr_t)(p.dtw + (size_t)(cdim0 + k_) * DTR);
 #pragma unroll
@@ -178,10 +190,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             }
         };
         auto param_load = [&](int k_, int chunk_) {
-            nAv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsA, 16 * row, 64 * k_, 0));
-            nck = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsCk, 16 * row, 64 * (k_ * nchunks + chunk_), 0));
-            nbias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsBi, 0, 4 * k_, 0));
-            nD = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDp, 0, 4 * k_, 0));
+            // (PACK: the second channel of an odd part's last unit lies past num_records and reads zeros)
+            const int kc_ = PACK ? 2 * k_ : k_;
+            nAv = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsA, 16 * row + 64 * half, 64 * kc_, 0));
+            nck = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rsCk, 16 * row + 64 * half * nchunks, 64 * (kc_ * nchunks + chunk_), 0));
+            nbias = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsBi, 4 * half, 4 * kc_, 0));
+            nD = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsDp, 4 * half, 4 * kc_, 0));
         };
         f4 tlo[NM], thi[NM];
         tile_load(nchunks - 1, tlo, thi);
@@ -212,8 +226,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int t = 0; t < T; ++t) { accB[pi][t] = f2{0.0f, 0.0f}; accC[pi][t] = f2{0.0f, 0.0f}; }
 
-            const int ps = base + 8 * seg + 2 * row;             // the two positions this lane stages and finishes
-            const bool ok0 = ps < L, ok1 = ps + 1 < L;
+            const int ps = base + 8 * sg + 2 * row;              // the two positions this lane stages and finishes
             // staging strip: [array][item pair p][segment] float2 -- the writer (row = p) and the readers (4 pairs of one
             // segment, one ds_read_b64 each) both touch 32 distinct banks per instruction
             const int sto = 32 * row + 2 * seg, sta = 2 * seg;
@@ -221,9 +234,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             int tk = 0;
             if (lane == 0) tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             int kt = __builtin_amdgcn_readfirstlane(tk);               // this wave's next channel, if there is one
-            for (int k = wave; k < n;) {
+            for (int k = wave; k < nu_;) {
                 SR_PROBE(0);
-                const bool lastk = kt >= n;
+                const bool lastk = kt >= nu_;
+                const bool live = !(odd_out && k == nu_ - 1);          // PACK: this lane's channel exists
+                const bool ok0 = ps < L && live, ok1 = ps + 1 < L && live;
                 const int kn = lastk ? kfirst : kt, chn = lastk ? chunk_next : chunk;
                 if (lane == 0) tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 const f2 cu = nu, cy = ny;
@@ -255,7 +270,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                         dyp[j] = *reinterpret_cast<const f2 *>(st + 2 * CHUNK + sta + 32 * j);
                     }
                 }
-                float *rec = recs + k * REC + 4 * row;                    // + 0: carries, + 16: dA, + 32: dD / dbias of this row
+                float *rec = recs + (PACK ? 2 * k + half : k) * REC + 4 * row;     // + 0: carries, + 16: dA, + 32: dD / dbias of this row
                 const f4 rcv = *reinterpret_cast<const f4 *>(rec);       // adjoint entering from the right
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -272,7 +287,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                 for (int pi = 0; pi < 2; ++pi) {
                     const int np = 2 * row + pi;
-                    const f4 *__restrict__ tB = tile + (np * 4) * 16 + seg, *__restrict__ tC = tB + 512;
+                    const f4 *__restrict__ tB = tile + (np * 4) * 16 + sg, *__restrict__ tC = tB + 512;
                     const f2 A2 = f2{Av[2 * pi], Av[2 * pi + 1]} * SS2D_LOG2E;
                     const f2 hin = f2{ck[2 * pi], ck[2 * pi + 1]};
                     const f2 rcar = f2{rcv[2 * pi], rcv[2 * pi + 1]};
@@ -290,15 +305,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                             bb[2 * j] = pk_mul_lo(dup[j], f2{Bq.x, Bq.y});
                             bb[2 * j + 1] = pk_mul_hi(dup[j], f2{Bq.z, Bq.w});
                         }
-                        f2 hl = f2{seg == 0 ? hin.x : 0.0f, seg == 0 ? hin.y : 0.0f};
+                        f2 hl = f2{sg == 0 ? hin.x : 0.0f, sg == 0 ? hin.y : 0.0f};
 #pragma unroll
                         for (int t = 0; t < T; ++t) hl = fma2(a[t], hl, bb[t]);
                         float hx = hl.x, hy = hl.y, ax = at.x, ay = at.y;
+                        if (PACK) { ax = seg == 8 ? 0.0f : ax; ay = seg == 8 ? 0.0f : ay; }      // nothing crosses from lane 7 into lane 8
 #pragma unroll
                         for (int j = 0; j < 4; ++j) Cq[j] = tC[j * 16];   // requested here: they arrive behind the row scan
                         row_scan_fwd_pair(hx, hy, ax, ay);
                         hstart.x = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(hin.x, hx);
                         hstart.y = dpp_mov<DPP_ROW_SHR(1), 0xf, false>(hin.y, hy);
+                        if (PACK) { hstart.x = seg == 8 ? hin.x : hstart.x; hstart.y = seg == 8 ? hin.y : hstart.y; }
                         f2 hh = hstart;
 #pragma unroll
                         for (int t = 0; t < T; ++t) { hh = fma2(a[t], hh, bb[t]); h[t] = hh; }
@@ -309,17 +326,19 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     f2 rr;
                     f4 Bn, Cn;
                     {
-                        f2 rl = f2{seg == 15 ? rcar.x : 0.0f, seg == 15 ? rcar.y : 0.0f};
+                        f2 rl = f2{sg == (PACK ? 7 : 15) ? rcar.x : 0.0f, sg == (PACK ? 7 : 15) ? rcar.y : 0.0f};
 #pragma unroll
                         for (int j = 3; j >= 0; --j) {
                             rl = a[2 * j + 1] * pk_fma_hi(dyp[j], f2{Cq[j].z, Cq[j].w}, rl);
                             rl = a[2 * j] * pk_fma_lo(dyp[j], f2{Cq[j].x, Cq[j].y}, rl);
                         }
                         float rx = rl.x, ry = rl.y, ax = at.x, ay = at.y;
+                        if (PACK) { ax = seg == 7 ? 0.0f : ax; ay = seg == 7 ? 0.0f : ay; }      // nothing crosses from lane 8 into lane 7
                         Bn = tB[3 * 16]; Cn = tC[3 * 16];                 // first operands of the true pass, behind the row scan
                         row_scan_rev_pair(rx, ry, ax, ay);
                         rr.x = dpp_mov<DPP_ROW_SHL(1), 0xf, false>(rcar.x, rx);
                         rr.y = dpp_mov<DPP_ROW_SHL(1), 0xf, false>(rcar.y, ry);
+                        if (PACK) { rr.x = seg == 7 ? rcar.x : rr.x; rr.y = seg == 7 ? rcar.y : rr.y; }
                     }
                     if (pi == 0) param_load(kn, chn);   // in flight during pair 1
                     __builtin_amdgcn_sched_barrier(0);
@@ -375,13 +394,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 if (p.softplus) { ddta *= sg0; ddtb *= sg1; }
                 ddta = ok0 ? ddta : 0.0f;
                 ddtb = ok1 ? ddtb : 0.0f;
-                buf_store2s<VEC, IO>(rsDu, ps, L, rev, f2{e0 * dtq.x + dyq.x * Dc, o0 * dtq.y + dyq.y * Dc}, k * (int)rowbytes);
-                buf_store2s<VEC, IO>(rsDd, ps, L, rev, f2{ddta, ddtb}, k * (int)rowbytes);
+                const int sso = (PACK ? 2 * k : k) * (int)rowbytes, sve = PACK ? (live ? half * (int)rowbytes : SS2D_BUF_OOR) : 0;
+                buf_store2s<VEC, IO>(rsDu, ps, L, rev, f2{e0 * dtq.x + dyq.x * Dc, o0 * dtq.y + dyq.y * Dc}, sso, sve);
+                buf_store2s<VEC, IO>(rsDd, ps, L, rev, f2{ddta, ddtb}, sso, sve);
                 SR_PROBE(13);
                 // ---- dA (4 states of this row), dD, ddelta_bias: row sums, accumulated over the chunks in the wave's LDS record
                 float s0 = dAp[0].x, s1 = dAp[0].y, s2 = dAp[1].x, s3 = dAp[1].y, sD = dyq.x * u0 + dyq.y * u1, sb = ddta + ddtb;
-                row_sum6_to_lane15(s0, s1, s2, s3, sD, sb);
-                if (seg == 15) {   // plain read-modify-write: the record is private to the wave
+                if (PACK) row_sum6_to_lanes7_15(s0, s1, s2, s3, sD, sb); else row_sum6_to_lane15(s0, s1, s2, s3, sD, sb);
+                if (sg == (PACK ? 7 : 15)) {   // plain read-modify-write: the record is private to the wave
                     f4 *qa = reinterpret_cast<f4 *>(rec + 16);
                     f2 *qd = reinterpret_cast<f2 *>(rec + 32);
                     const f4 va = *qa;
@@ -389,7 +409,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                     *qa = va + f4{s0, s1, s2, s3};
                     *qd = vd + f2{sD, sb};
                 }
-                if (seg == 0) *reinterpret_cast<f4 *>(rec) = f4{rleft[0].x, rleft[0].y, rleft[1].x, rleft[1].y};
+                if (sg == 0) *reinterpret_cast<f4 *>(rec) = f4{rleft[0].x, rleft[0].y, rleft[1].x, rleft[1].y};
                 k = kt;
                 kt = kt2;
             }
@@ -399,6 +419,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             SR_PROBE(11);
             __syncthreads();   // every wave is done with the tile
             SR_PROBE(14);
+            if (PACK) {   // lane s takes over lane s + 8's sums: the same 8 positions, the wave's other channel
+#pragma unroll
+                for (int pi = 0; pi < 2; ++pi)
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        accB[pi][t].x += dpp_mov<DPP_ROW_SHL(8), 0xf, true>(0.0f, accB[pi][t].x);
+                        accB[pi][t].y += dpp_mov<DPP_ROW_SHL(8), 0xf, true>(0.0f, accB[pi][t].y);
+                        accC[pi][t].x += dpp_mov<DPP_ROW_SHL(8), 0xf, true>(0.0f, accC[pi][t].x);
+                        accC[pi][t].y += dpp_mov<DPP_ROW_SHL(8), 0xf, true>(0.0f, accC[pi][t].y);
+                    }
+            }
             // ---- this wave's dB / dC sums -> its slot, [matrix][state][position], halves swizzled against bank conflicts
             {
                 const int l2 = opaque_tid() & 63, row2 = l2 >> 4, seg2 = l2 & 15, sw = ((seg2 >> 2) & 1) << 2;
@@ -499,9 +530,9 @@ __global__ __launch_bounds__(256) void scan_bwd_sr_reduce_packed_kernel(const fl
     st4(dxdbl + (size_t)bg * bcs + (size_t)R * L + 4 * (size_t)i, acc);
 }
 
-template <bool VEC, typename IO, bool DIRS, bool WS, int DTR = 0>
+template <bool VEC, typename IO, bool DIRS, bool WS, int DTR = 0, bool PACK = false>
 int launch_sr(const ScanBwdParams &p, int nwg, hipStream_t s) {
-    auto kern = scan_bwd_sr_kernel<VEC, IO, DIRS, WS, DTR>;
+    auto kern = scan_bwd_sr_kernel<VEC, IO, DIRS, WS, DTR, PACK>;
     static bool attr_set[SS2D_MAX_DEVICES] = {};   // per instantiation and device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SS2D_MAX_DEVICES) dev = 0;
@@ -584,11 +615,16 @@ int ss2d_scan_bwd_sr_launch(int dtype, ScanBwdParams p, bool vec4, bool dirs, fl
     p.ws = (ws && (p.L % 4 == 0) && (((uintptr_t)ws | (uintptr_t)p.dB | (uintptr_t)p.dC | (uintptr_t)p.dxdbl) & 15) == 0 &&
             ws_bytes >= ss2d_scan_bwd_sr_ws_bytes(p.batch, p.dim, p.L, p.G)) ? ws : nullptr;
     int rc;
+    static const bool env_nopack = getenv("SS2D_BWD_NO_PACK") != nullptr;      // A/B switch, read once
     if (p.dtw) {   // fused delta: only the form SS2D issues (4-element rows, direction-aware, workspace), ranks 6 and 12
         if (!p.ws || !vec4 || (p.R != 6 && p.R != 12)) return (int)hipErrorInvalidValue;
         const bool h = dtype == SS2D_DTYPE_BF16;
         if (p.R == 6) rc = h ? launch_sr<true, bf16, true, true, 6>(p, (int)nwg, s) : launch_sr<true, float, true, true, 6>(p, (int)nwg, s);
         else rc = h ? launch_sr<true, bf16, true, true, 12>(p, (int)nwg, s) : launch_sr<true, float, true, true, 12>(p, (int)nwg, s);
+    } else if (p.ws && vec4 && p.nchunks == 1 && p.L <= CHUNK / 2 && !env_nopack) {
+        // sequences that fit half a row (the 7 x 7 / 8 x 8 stages): two channels per wave at a time
+        if (dtype == SS2D_DTYPE_BF16) rc = dirs ? launch_sr<true, bf16, true, true, 0, true>(p, (int)nwg, s) : launch_sr<true, bf16, false, true, 0, true>(p, (int)nwg, s);
+        else rc = dirs ? launch_sr<true, float, true, true, 0, true>(p, (int)nwg, s) : launch_sr<true, float, false, true, 0, true>(p, (int)nwg, s);
     } else if (dtype == SS2D_DTYPE_BF16) {
         if (dirs) rc = vec4 ? launch_sr_ws<true, bf16, true>(p, (int)nwg, s) : launch_sr_ws<false, bf16, true>(p, (int)nwg, s);
         else rc = vec4 ? launch_sr_ws<true, bf16, false>(p, (int)nwg, s) : launch_sr_ws<false, bf16, false>(p, (int)nwg, s);
