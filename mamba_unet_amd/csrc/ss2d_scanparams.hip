@@ -94,73 +94,68 @@ struct BlockParamsArgs {
     int Cx, ldD, ldC, ldR;
 };
 
+// (32-bit index arithmetic throughout: the host checks the element count; 64-bit divisions made this 6.5 us per launch)
 template <typename IO, bool BWD>
 __global__ __launch_bounds__(256) void block_params_kernel(const BlockParamsArgs q) {
     const ScanParamsArgs &p = q.sp;
-    const int Dm = p.Dm, R = p.R, Cx = q.Cx;
-    const long long n0 = (long long)4 * Dm * (p.N + 2 + R);
-    const long long n1 = BWD ? (long long)4 * Cx * Dm : (long long)2 * 2 * Cx * q.ldD;   // xw (bwd: d x_proj_weight)
-    const long long n2 = BWD ? 0 : (long long)2 * Dm * q.ldC;                              // xwT
-    const long long n3 = BWD ? 0 : (long long)4 * R * q.ldD;                               // dtwT
-    const long long n4 = (BWD || !q.dtwio) ? 0 : (long long)4 * Dm * q.ldR;                // dt weight in the IO type
-    const long long total = n0 + n1 + n2 + n3 + n4;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const unsigned Dm = p.Dm, R = p.R, N = p.N, Cx = q.Cx, ldD = q.ldD, ldC = q.ldC, ldR = q.ldR;
+    const unsigned n0 = 4u * Dm * (N + 2 + R);
+    const unsigned n1 = BWD ? 4u * Cx * Dm : 4u * Cx * ldD;             // xw (bwd: d x_proj_weight)
+    const unsigned n2 = BWD ? 0u : 2u * Dm * ldC;                       // xwT
+    const unsigned n3 = BWD ? 0u : 4u * R * ldD;                        // dtwT
+    const unsigned n4 = (BWD || !q.dtwio) ? 0u : 4u * Dm * ldR;         // dt weight in the IO type
+    const unsigned total = n0 + n1 + n2 + n3 + n4;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
         if (i < n0) {   // as scan_params_kernel
-            const int per_row = p.N + 2 + R;
-            const int e = (int)(i % per_row);
-            const long long row = i / per_row;
-            const int g = (int)(row / Dm), d = (int)(row % Dm);
-            const long long other = (long long)src_group(g, 1) * Dm + d;
-            if (e < p.N) {
-                if (!BWD) p.oa[row * p.N + e] = -expf(p.a[other * p.N + e]);
-                else p.oa[other * p.N + e] = p.a ? p.a[row * p.N + e] * p.A[row * p.N + e] : 0.0f;
-            } else if (e == p.N) {
+            const unsigned per_row = N + 2 + R;
+            const unsigned row = i / per_row, e = i - row * per_row;
+            const unsigned g = row / Dm, d = row - g * Dm;
+            const unsigned other = (unsigned)src_group((int)g, 1) * Dm + d;
+            if (e < N) {
+                if (!BWD) p.oa[row * N + e] = -expf(p.a[other * N + e]);
+                else p.oa[other * N + e] = p.a ? p.a[row * N + e] * p.A[row * N + e] : 0.0f;
+            } else if (e == N) {
                 if (!BWD) p.od[row] = p.d[other]; else p.od[other] = p.d ? p.d[row] : 0.0f;
-            } else if (e == p.N + 1) {
+            } else if (e == N + 1) {
                 if (!BWD) p.ob[row] = p.b[other]; else p.ob[other] = p.b ? p.b[row] : 0.0f;
             } else {
-                const int r = e - p.N - 2;
+                const unsigned r = e - N - 2;
                 if (!BWD) p.ow[row * R + r] = p.w[other * R + r]; else p.ow[other * R + r] = p.w ? p.w[row * R + r] : 0.0f;
             }
             continue;
         }
-        long long j = i - n0;
+        unsigned j = i - n0;
         if (BWD) {      // d x_proj_weight[k = 2 rev + o][c][d] = d_xw[o][rev Cx + c][d]
-            const int d = (int)(j % Dm);
-            const long long rowk = j / Dm;
-            const int c = (int)(rowk % Cx), k = (int)(rowk / Cx), o = k & 1, rev = k >> 1;
-            q.dxw[j] = q.xw_src ? q.xw_src[((long long)o * 2 * Cx + rev * Cx + c) * Dm + d] : 0.0f;
+            const unsigned rowk = j / Dm, d = j - rowk * Dm;
+            const unsigned k = rowk / Cx, c = rowk - k * Cx, o = k & 1, rev = k >> 1;
+            q.dxw[j] = q.xw_src ? q.xw_src[((o * 2 + rev) * Cx + c) * Dm + d] : 0.0f;
             continue;
         }
         if (j < n1) {   // xw[o][m = rev Cx + c][d], zero for d >= Dm
-            const int d = (int)(j % q.ldD);
-            const long long rowm = j / q.ldD;
-            const int m = (int)(rowm % (2 * Cx)), o = (int)(rowm / (2 * Cx)), rev = m / Cx, c = m - rev * Cx;
-            st1(static_cast<IO *>(q.xw) + j, d < Dm ? q.xw_src[((long long)(2 * rev + o) * Cx + c) * Dm + d] : 0.0f);
+            const unsigned rowm = j / ldD, d = j - rowm * ldD;
+            const unsigned o = rowm / (2 * Cx), m = rowm - o * 2 * Cx, rev = m >= Cx ? 1u : 0u, c = m - rev * Cx;
+            st1(static_cast<IO *>(q.xw) + j, d < Dm ? q.xw_src[((2 * rev + o) * Cx + c) * Dm + d] : 0.0f);
             continue;
         }
         j -= n1;
         if (j < n2) {   // xwT[o][d][m], zero for m >= 2 Cx
-            const int m = (int)(j % q.ldC);
-            const long long rowd = j / q.ldC;
-            const int d = (int)(rowd % Dm), o = (int)(rowd / Dm), rev = m / Cx, c = m - rev * Cx;
-            st1(static_cast<IO *>(q.xwT) + j, m < 2 * Cx ? q.xw_src[((long long)(2 * rev + o) * Cx + c) * Dm + d] : 0.0f);
+            const unsigned rowd = j / ldC, m = j - rowd * ldC;
+            const unsigned o = rowd / Dm, d = rowd - o * Dm, rev = m >= Cx ? 1u : 0u, c = m - rev * Cx;
+            st1(static_cast<IO *>(q.xwT) + j, m < 2 * Cx ? q.xw_src[((2 * rev + o) * Cx + c) * Dm + d] : 0.0f);
             continue;
         }
         j -= n2;
         if (j < n3) {   // dtwT[g][r][d], zero for d >= Dm
-            const int d = (int)(j % q.ldD);
-            const long long rowr = j / q.ldD;
-            const int r = (int)(rowr % R), g = (int)(rowr / R);
-            st1(static_cast<IO *>(q.dtwT) + j, d < Dm ? p.w[((long long)src_group(g, 1) * Dm + d) * R + r] : 0.0f);
+            const unsigned rowr = j / ldD, d = j - rowr * ldD;
+            const unsigned g = rowr / R, r = rowr - g * R;
+            st1(static_cast<IO *>(q.dtwT) + j, d < Dm ? p.w[((unsigned)src_group((int)g, 1) * Dm + d) * R + r] : 0.0f);
             continue;
         }
         j -= n3;
         {               // dt weight [g][d][r] in the IO type, zero for r >= R
-            const int r = (int)(j % q.ldR);
-            const long long row = j / q.ldR;
-            const int d = (int)(row % Dm), g = (int)(row / Dm);
-            st1(static_cast<IO *>(q.dtwio) + j, r < R ? p.w[((long long)src_group(g, 1) * Dm + d) * R + r] : 0.0f);
+            const unsigned row = j / ldR, r = j - row * ldR;
+            const unsigned g = row / Dm, d = row - g * Dm;
+            st1(static_cast<IO *>(q.dtwio) + j, r < R ? p.w[((unsigned)src_group((int)g, 1) * Dm + d) * R + r] : 0.0f);
         }
     }
 }
@@ -182,6 +177,7 @@ extern "C" int ss2d_block_params_fwd(int dtype, const float *A_logs, const float
     q.xw_src = x_w; q.xw = xw; q.xwT = xwT; q.dtwT = dtwT; q.dtwio = dtw_io; q.Cx = Cx; q.ldD = ldD; q.ldC = ldC; q.ldR = ldR;
     const long long total = (long long)4 * Dm * (N + 2 + R) + (long long)4 * Cx * ldD + (long long)2 * Dm * ldC + (long long)4 * R * ldD +
                             (dtw_io ? (long long)4 * Dm * ldR : 0);
+    if (total >= (1ll << 31)) { ss2d_set_error("block_params_fwd: more than 2^31 elements"); return -6; }
     long long nwg = (total + 255) / 256;
     if (nwg > 2048) nwg = 2048;
     hipStream_t s = (hipStream_t)stream;
@@ -202,6 +198,7 @@ extern "C" int ss2d_block_params_bwd(const float *A, const float *dA, const floa
     q.sp.K = 4; q.sp.Dm = Dm; q.sp.N = N; q.sp.R = R; q.sp.swap = 1;
     q.xw_src = d_xw; q.dxw = dx_w; q.Cx = R + 2 * N;
     const long long total = (long long)4 * Dm * (N + 2 + R) + (long long)4 * q.Cx * Dm;
+    if (total >= (1ll << 31)) { ss2d_set_error("block_params_bwd: more than 2^31 elements"); return -6; }
     long long nwg = (total + 255) / 256;
     if (nwg > 2048) nwg = 2048;
     ss2d_launch((block_params_kernel<float, true>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, q);

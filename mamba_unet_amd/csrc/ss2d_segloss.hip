@@ -96,15 +96,33 @@ __global__ __launch_bounds__(256) void seg_loss_stats_kernel(const IO *__restric
         partials[(size_t)blockIdx.x * (3 * C + 1) + threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// stats[j] = sum over the workgroup rows, in a fixed order: 4 lanes per statistic, each a strided run, then a fixed tree
-__global__ __launch_bounds__(256) void seg_loss_finish_kernel(const float *__restrict__ partials, float *__restrict__ stats, int nstat, int nrows) {
-    const int j = threadIdx.x >> 2, part = threadIdx.x & 3;
-    float s = 0.0f;
-    if (j < nstat)
-        for (int r = part; r < nrows; r += 4) s += partials[(size_t)r * nstat + j];
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    if (j < nstat && part == 0) stats[j] = s;
+// stats[j] = sum over the workgroup rows, in a fixed order.  One 1024-thread workgroup: wave w walks the rows w, w + 16, ...
+// with lane j on statistic j (a row is one coalesced run of 3C + 1 <= 64 floats), eight independent partial sums per lane
+// so that eight loads are in flight, combined in a fixed tree; the 16 wave sums are added in wave order by wave 0.  (The
+// first version gave each statistic 4 lanes walking 256 rows each with one dependent load per trip: 63 us.)
+__global__ __launch_bounds__(1024) void seg_loss_finish_kernel(const float *__restrict__ partials, float *__restrict__ stats, int nstat, int nrows) {
+    __shared__ float red[16][64];
+    const int j = threadIdx.x & 63, w = threadIdx.x >> 6;
+    float a[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] = 0.0f;
+    if (j < nstat) {
+        for (int r0 = w; r0 < nrows; r0 += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + 16 * u;
+                a[u] += partials[(size_t)(r < nrows ? r : 0) * nstat + j] * (r < nrows ? 1.0f : 0.0f);
+            }
+        }
+    }
+    red[w][j] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (w == 0 && j < nstat) {
+        float s = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[q][j];
+        stats[j] = s;
+    }
 }
 
 // dlogits[c] = p_c * (q_c - sum_k p_k q_k) + g_ce * (p_c - [y == c]),  q_c = g_inter[c] * [y == c] + 2 * g_z[c] * p_c
@@ -203,7 +221,7 @@ extern "C" int ss2d_seg_loss_stats(int dtype, const void *logits, const void *la
         else { if (h) SS2D_SEG_STATS(16, 1, bf16); else SS2D_SEG_STATS(16, 1, float); }
     }
 #undef SS2D_SEG_STATS
-    ss2d_launch(seg_loss_finish_kernel, dim3(1), dim3(256), 0, s, (const float *)workspace, stats, 3 * C + 1, (int)g.nwg);
+    ss2d_launch(seg_loss_finish_kernel, dim3(1), dim3(1024), 0, s, (const float *)workspace, stats, 3 * C + 1, (int)g.nwg);
     rc = ss2d_take_launch_rc();
     if (rc) ss2d_set_error("seg_loss_stats: launch failed: %s", hipGetErrorString((hipError_t)rc));
     return rc;
