@@ -69,25 +69,38 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
     u32x4 wr[DEEP ? 2 : 1][NWP];
     constexpr std::integral_constant<int, 0> S0{};
     constexpr std::integral_constant<int, 1> S1{};
+    // Operands through buffer descriptors: X ends behind its K rows (a chunk row past K reads zeros by the range check), W behind
+    // the block's rows; a column past L / a k past ldw is sent out of range by its offset.  Nothing touches a loaded value
+    // before its ds_write -- the first version zeroed those pieces with an AND on the value, and in the two-deep form the
+    // compiler gathered the ANDs of both register sets behind one s_waitcnt vmcnt(0) per trip (see ss2d_wgrad.hip).
+    // (Host: K * L and 96 * ldw elements stay below 2^30.)
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(Xg, (unsigned)p.K * (unsigned)L * 2u);
+    const int wrows = p.M - m0 < BM ? p.M - m0 : BM;
+    const __amdgpu_buffer_rsrc_t rsW = make_rsrc(Wg, (unsigned)wrows * (unsigned)p.ldw * 2u);
+    int xofs[NXP], wofs[NWP], wk[NWP];
+#pragma unroll
+    for (int j = 0; j < NXP; ++j) {
+        const int id = j * 256 + tid, row = id / XPR, pc = id - row * XPR;
+        const int col = l0 + pc * XE;
+        xofs[j] = col < L ? (row * L + col) * 2 : SS2D_BUF_OOR;
+    }
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) {
+        const int id = j * 256 + tid, row = id / WPR, pc = id - row * WPR;
+        wk[j] = pc * 8;
+        wofs[j] = row < wrows ? (row * p.ldw + pc * 8) * 2 : SS2D_BUF_OOR;
+    }
     auto load_chunk = [&](auto set, int c) {                 // a chunk past K reads as zeros
         constexpr int S = DEEP ? decltype(set)::value : 0;
-        // never a guarded load: the address is clamped to element 0 and the value masked
+        const int sx = c * KC * L * 2, sw = c * KC * 2;
 #pragma unroll
         for (int j = 0; j < NXP; ++j) {
-            const int id = j * 256 + tid, row = id / XPR, pc = id - row * XPR;
-            const int k = c * KC + row, col = l0 + pc * XE;
-            const bool ok = k < p.K && col < L;
-            const xpiece_t v = *reinterpret_cast<const xpiece_t *>(Xg + (ok ? (size_t)k * L + col : 0));
-            xr[S][j] = v & (ok ? ~0u : 0u);
+            if constexpr (V16) xr[S][j] = __builtin_bit_cast(xpiece_t, __builtin_amdgcn_raw_buffer_load_b128(rsX, xofs[j], sx, 0));
+            else xr[S][j] = __builtin_bit_cast(xpiece_t, __builtin_amdgcn_raw_buffer_load_b64(rsX, xofs[j], sx, 0));
         }
 #pragma unroll
-        for (int j = 0; j < NWP; ++j) {
-            const int id = j * 256 + tid, row = id / WPR, pc = id - row * WPR;
-            const int k = c * KC + pc * 8;
-            const bool ok = row < BM && m0 + row < p.M && k < p.ldw;
-            const u32x4 v = *reinterpret_cast<const u32x4 *>(Wg + (ok ? (size_t)row * p.ldw + k : 0));
-            wr[S][j] = v & (ok ? ~0u : 0u);
-        }
+        for (int j = 0; j < NWP; ++j)
+            wr[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsW, c * KC + wk[j] < p.ldw ? wofs[j] : SS2D_BUF_OOR, sw, 0);
     };
     auto put_chunk = [&](auto set, int stage) {
         constexpr int S = DEEP ? decltype(set)::value : 0;
@@ -133,6 +146,7 @@ __global__ __launch_bounds__(256) void cm_gemm_kernel(const CgParams p) {
     };
     if constexpr (DEEP) {
         load_chunk(S0, 0);
+        __builtin_amdgcn_sched_barrier(0);     // set 0's loads in front of set 1's: interleaved, the first put of every trip waits for both
         load_chunk(S1, 1);
         // two chunks per trip, nothing under a branch (an odd count ends with a chunk of zeros); a stage was last read two
         // chunks ago, behind the previous barrier
@@ -310,6 +324,8 @@ extern "C" int ss2d_chan_gemm(int dtype, const void *W, const void *X, void *Y, 
     const int mblocks = (M + bm - 1) / bm, ntiles = (L + BN - 1) / BN;
     const long long nwg = (long long)B * G * mblocks * ntiles;
     if (nwg > 0x7fffffffLL) { ss2d_set_error("chan_gemm: grid too large"); return -6; }
+    if (!f32 && ((long long)(K + 256) * L >= (1ll << 30) || (long long)BM * ldw >= (1ll << 30))) {   // 32-bit byte offsets inside a (b, g) block
+        ss2d_set_error("chan_gemm: a (batch, group) block of X of 2 GB or more"); return -6; }
     if (f32) {
         CgParamsF p;
         p.W = static_cast<const float *>(W); p.X = static_cast<const float *>(X); p.Y = static_cast<float *>(Y);
