@@ -188,6 +188,9 @@ int ss2d_dirs_gather_ld(int dtype, int layout, const void *ys, void *y, int B, i
                         long long row_pitch, void *stream);
 int ss2d_dirs_gather6_ld(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, long long row_pitch,
                          void *stream);
+/* ... with y channel-last (B, H, W, D): dy of a channel-last convolution output (ss2d_dwconv3x3_silu_cl_bwd below). */
+int ss2d_dirs_gather6_cl_ld(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, long long row_pitch,
+                            void *stream);
 
 /* Depthwise 3x3 conv (pad 1, bias) + SiLU (mamba_sys.py:299-308, :558-559).
  *   x: channel_last_in ? (B, H, W, ldx) with the D channels first (ldx >= D lets it read the x half of
@@ -199,6 +202,15 @@ int ss2d_dwconv3x3_silu_fwd(int dtype, const void *x, const float *w, const floa
 int ss2d_dwconv3x3_silu_bwd(int dtype, const void *x, const float *w, const float *bias, const void *dy,
                             void *dx, float *dw, float *dbias, int B, int D, int H, int W, int channel_last_in,
                             int ldx, int lddx, void *stream);
+/* The same convolution with channel-last tensors on both sides (mamba_sys.py:299-308, :558-559 without the permute of
+ * :558 and without its inverse in the backward): x (B, H, W, ldx), y (B, H, W, ldy), dy (B, H, W, lddy), dx (B, H, W, lddx),
+ * the D channels first in every pixel, pitches >= D.  D and the pitches multiples of 4, pointers aligned to 4 elements
+ * (w, bias to 16 bytes); one image below 2 GB.  dw / dbias accumulated with float atomics (caller zero-fills). */
+int ss2d_dwconv3x3_silu_cl_fwd(int dtype, const void *x, const float *w, const float *bias, void *y, int B, int D,
+                               int H, int W, int ldx, int ldy, void *stream);
+int ss2d_dwconv3x3_silu_cl_bwd(int dtype, const void *x, const float *w, const float *bias, const void *dy, void *dx,
+                               float *dw, float *dbias, int B, int D, int H, int W, int ldx, int lddy, int lddx,
+                               void *stream);
 
 /* dt_proj forward (mamba_sys.py:420, weight :319-327): out[b,g,d,l] = sum_r w[g,d,r] * x[b,g,r,l], R = dt_rank in
  * {6, 12} (stages 0 and 1 of Mamba-UNet; other ranks: use a library GEMM).  x is read in place from the first R rows

@@ -37,6 +37,9 @@ _SIGNATURES = {
     "ss2d_dirs_scatter_ld": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_longlong, _vp]),
     "ss2d_dirs_gather_ld": (_i, [_i, _i, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_longlong, _vp]),
     "ss2d_dirs_gather6_ld": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_longlong, _vp]),
+    "ss2d_dirs_gather6_cl_ld": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, ctypes.c_longlong, _vp]),
+    "ss2d_dwconv3x3_silu_cl_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ss2d_dwconv3x3_silu_cl_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ss2d_dwconv3x3_silu_fwd": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "ss2d_dwconv3x3_silu_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "ss2d_dt_proj_fwd": (_i, [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.c_longlong, _vp]),

@@ -366,13 +366,13 @@ void launch(bool merge, bool cl, bool h, dim3 grid, hipStream_t s, const CrossPa
         else    { if (h) ss2d_launch((K<false, bf16, T, ##__VA_ARGS__>), grid, block, 0, s, p); else ss2d_launch((K<false, float, T, ##__VA_ARGS__>), grid, block, 0, s, p); } \
     } while (0)
     if constexpr (E == 0) {
-        if (merge && p.in2) {   // 4 + 2 slots -> channel-first image (the one shape the backward needs)
-            if (h) ss2d_launch((cross_merge_kernel<false, bf16, T, true>), grid, block, 0, s, p); else ss2d_launch((cross_merge_kernel<false, float, T, true>), grid, block, 0, s, p);
+        if (merge && p.in2) {   // 4 + 2 slots -> image (the backward of an SS2D call)
+            SS2D_CROSS_LAUNCH(cross_merge_kernel, true);
         } else if (merge) SS2D_CROSS_LAUNCH(cross_merge_kernel);
         else SS2D_CROSS_LAUNCH(cross_scan_kernel);
     } else {
         if (merge && p.in2) {
-            if (h) ss2d_launch((cross_merge_vec_kernel<false, bf16, T, true, E>), grid, block, 0, s, p); else ss2d_launch((cross_merge_vec_kernel<false, float, T, true, E>), grid, block, 0, s, p);
+            SS2D_CROSS_LAUNCH(cross_merge_vec_kernel, true, E);
         } else if (merge) SS2D_CROSS_LAUNCH(cross_merge_vec_kernel, false, E);
         else SS2D_CROSS_LAUNCH(cross_scan_vec_kernel, E);
     }
@@ -455,4 +455,10 @@ extern "C" int ss2d_dirs_gather6_ld(int dtype, const void *ys4, const void *ys2,
                                     void *stream) {
     if (!ys2) { ss2d_set_error("dirs_gather6_ld: null pointer"); return -2; }
     return run(true, false, SS2D_DIRS_MIRROR_FREE_4, dtype, ys4, y, B, D, H, W, stream, "dirs_gather6_ld", ys2, row_pitch);
+}
+// ... with y channel-last (B, H, W, D): the gradient of a channel-last convolution output (ss2d_dwconv3x3_silu_cl_bwd)
+extern "C" int ss2d_dirs_gather6_cl_ld(int dtype, const void *ys4, const void *ys2, void *y, int B, int D, int H, int W, long long row_pitch,
+                                       void *stream) {
+    if (!ys2) { ss2d_set_error("dirs_gather6_cl_ld: null pointer"); return -2; }
+    return run(true, true, SS2D_DIRS_MIRROR_FREE_4, dtype, ys4, y, B, D, H, W, stream, "dirs_gather6_cl_ld", ys2, row_pitch);
 }

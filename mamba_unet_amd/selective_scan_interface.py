@@ -254,8 +254,9 @@ class ScanCoreFn(torch.autograd.Function):
     PACKED_DXDBL = not _os.environ.get("SS2D_NO_PACKED_DXDBL")
 
     @staticmethod
-    def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None, dtwT=None, dtw_io=None):
+    def forward(ctx, u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None, dtwT=None, dtw_io=None, x_channel_last=False):
         ctx.holder = holder
+        ctx.x_cl = bool(x_channel_last)
         if not x_dbl.is_cuda:
             raise RuntimeError("scan_core_fn: GPU tensors required (no CPU path in mamba_unet_amd)")
         batch, K, Cx, L = x_dbl.shape
@@ -263,8 +264,8 @@ class ScanCoreFn(torch.autograd.Function):
         dim = 4 * Dch
         if K != 4 or Cx != R + 2 * N or L < H * W or u2.shape != (batch, 2 * Dch, L) or dt_w.shape[0] != 4 or A.shape[0] != dim:
             raise ValueError(f"scan_core_fn: inconsistent shapes u {tuple(u2.shape)} x_dbl {tuple(x_dbl.shape)} dt_w {tuple(dt_w.shape)}")
-        if x is not None and tuple(x.shape) != (batch, Dch, H, W):
-            raise ValueError(f"scan_core_fn: x {tuple(x.shape)} is not (batch, d, H, W) = {(batch, Dch, H, W)}")
+        if x is not None and tuple(x.shape) != ((batch, H, W, Dch) if x_channel_last else (batch, Dch, H, W)):
+            raise ValueError(f"scan_core_fn: x {tuple(x.shape)} is not (batch, d, H, W) = {(batch, Dch, H, W)} (or channel-last with x_channel_last)")
         io = torch.bfloat16 if x_dbl.dtype == torch.bfloat16 else torch.float32
         code = _BF16 if io == torch.bfloat16 else _F32
         u_, xd, w32 = _prep(u2, "u", io), _prep(x_dbl, "x_dbl", io), _prep(dt_w, "dt_w")
@@ -366,8 +367,8 @@ class ScanCoreFn(torch.autograd.Function):
                 # (ss2d_ops.GradSlots); x gets no gradient from this node then
                 ctx.holder.du = du
             elif x_dt is not None:      # all four directions' du -> dx in one pass (the adjoint of the scatter)
-                dx = torch.empty((batch, Dch, H, W), device=dev, dtype=io)
-                rc = lib.ss2d_dirs_gather_ld(code, 1, _lib.ptr(du), _lib.ptr(dx), batch, Dch, H, W, 0, L, _stream())
+                dx = torch.empty((batch, H, W, Dch) if ctx.x_cl else (batch, Dch, H, W), device=dev, dtype=io)
+                rc = lib.ss2d_dirs_gather_ld(code, 1, _lib.ptr(du), _lib.ptr(dx), batch, Dch, H, W, int(ctx.x_cl), L, _stream())
                 _lib.check(rc, "ss2d_dirs_gather_ld")
             else:
                 du2 = du.view(batch, 2, 2, Dch, L).sum(2).view(batch, 2 * Dch, L)
@@ -393,14 +394,14 @@ class ScanCoreFn(torch.autograd.Function):
                 dts_rows.copy_(d_dts)
         cast = lambda t, d: None if t is None else t.to(d)  # noqa: E731
         return (cast(du2, u_dt), cast(d_xdbl, xdbl_dt), cast(d_w, w_dt), cast(dA, A_dt), cast(dD, D_dt), cast(dbias, b_dt),
-                None, None, cast(dx, x_dt), None, None, None)
+                None, None, cast(dx, x_dt), None, None, None, None)
 
 
-def scan_core_fn(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None, dtwT=None, dtw_io=None):
+def scan_core_fn(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x=None, holder=None, dtwT=None, dtw_io=None, x_channel_last=False):
     """u2 (b, 2*d, l): row-major and column-major copies of x; x_dbl (b, 4, R+2N, l): the x_proj output with rows
     [dts | B | C] per scan group; dt_w (4, d, R); A (4*d, n), D, delta_bias (4*d) -- all in scan-group order
     (row-major, row-major reversed, column-major, column-major reversed).  delta = dt_w @ dts, softplus(delta + bias)
     as in SS2D.  l may exceed H*W: rows padded by the caller, u2 zero in the pad (SS2D._scan_core_dirs).  Returns y
     (b, H, W, d) = CrossMerge of the four scans.  dtwT (4, R, d) / dtw_io (4, d, R): optional prepared copies of dt_w in the
     activations' dtype with 16-byte padded rows (ss2d_ops.block_params), used in place by the dt_proj GEMMs."""
-    return ScanCoreFn.apply(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x, holder, dtwT, dtw_io)
+    return ScanCoreFn.apply(u2, x_dbl, dt_w, A, D, delta_bias, H, W, x, holder, dtwT, dtw_io, x_channel_last)

@@ -133,12 +133,16 @@ class SS2D(nn.Module):
 
     _GROUP_ORDER = (0, 2, 1, 3)   # scan group -> reference direction k (row-major, its reversal, column-major, its reversal)
 
-    def _scan_core_dirs(self, x: torch.Tensor):
+    def _scan_core_dirs(self, x: torch.Tensor, channel_last: bool = False):
         """Same function as _scan_core with the direction permutations folded into the scan's loads and stores:
         only the row-major and the column-major copy of x are materialised (2 of the 4 `xs` slices of :403-404), the
         reversed directions read them backwards in place, x_proj runs once per orientation with the two directions'
-        weights stacked (M = 2*(R+2N)), and the scan output is merged without un-flipping."""
-        B, D, H, W = x.shape
+        weights stacked (M = 2*(R+2N)), and the scan output is merged without un-flipping.  `channel_last`: x is (B, H, W, D),
+        as the channel-last convolution leaves it (SS2D.forward)."""
+        if channel_last:
+            B, H, W, D = x.shape
+        else:
+            B, D, H, W = x.shape
         L, N, R = H * W, self.d_state, self.dt_rank
         Cx = R + 2 * N
         # reference direction k = 2*rev + orientation  ->  scan group 2*orientation + rev: swap the two index bits
@@ -151,7 +155,9 @@ class SS2D(nn.Module):
             # first real position, a forward scan reaches the pad behind the last one; x_dbl and dy are 0 in the pad, so no
             # parameter gradient sees it, and the gathers read the H*W real positions only.
             L = (L + 7) // 8 * 8
-        xs2 = dirs_scatter2(x, slots, L)                                                        # (B, 2, D, L)
+        if channel_last and not (core and x.is_cuda):
+            x, channel_last = x.permute(0, 3, 1, 2), False      # the literal composition below wants (B, D, H, W)
+        xs2 = dirs_scatter2(x, slots, L, channel_last)                                          # (B, 2, D, L)
         if core and x.is_cuda and self.x_proj_weight.dtype == torch.float32 and not os.environ.get("SS2D_NO_BLOCK_PARAMS"):
             # every parameter-derived operand of the call from one launch (forward) / into one launch (backward): the
             # stacked x_proj weight [orientation][rev*Cx + c], its transpose, dt_w and its transpose in the activations'
@@ -159,23 +165,26 @@ class SS2D(nn.Module):
             A, Dv, bias, dt_w, xw, xwT, dtwT, dtw_io, pg = block_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight,
                                                                          self.x_proj_weight, x.dtype, want_dtw_io=R not in (6, 12))
             x_dbl = x_proj(xw, xs2, xwT, pg).view(B, 4, Cx, L)                          # group = 2*orientation + rev
-            return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x, holder=slots, dtwT=dtwT, dtw_io=dtw_io)
+            return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x, holder=slots, dtwT=dtwT, dtw_io=dtw_io,
+                                x_channel_last=channel_last)
         w_cat = self.x_proj_weight.view(2, 2, Cx, D).transpose(0, 1).reshape(2, 2 * Cx, D)     # [orientation][rev*Cx + c]
         x_dbl = x_proj(w_cat, xs2).view(B, 4, Cx, L)                                    # group = 2*orientation + rev
         A, Dv, bias, dt_w = scan_params(self.A_logs, self.Ds, self.dt_projs_bias, self.dt_projs_weight, regroup=True)
         if core:
             # dt_proj + scan + merge as one node reading x_dbl in place (rows [dts | B | C] of every block)
-            return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x, holder=slots)
+            return scan_core_fn(xs2.reshape(B, 2 * D, L), x_dbl, dt_w, A, Dv, bias, H, W, x=x, holder=slots, x_channel_last=channel_last)
         # the reference's fp32 casts around the scan (:423-426) under autocast
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = dt_proj(dts, dt_w)                                                                # (B, 4, D, L)
         return scan_merge_fn(xs2.float().reshape(B, 2 * D, L), dts.float().reshape(B, 4 * D, L), A,
                              Bs.float(), Cs.float(), Dv, bias, H, W, x=x)
 
-    def _scan_core(self, x: torch.Tensor):
+    def _scan_core(self, x: torch.Tensor, channel_last: bool = False):
         """forward_corev0 up to (not including) out_norm: x (B, D, H, W) -> merged y (B, H, W, D)."""
         if self.fused_directions:
-            return self._scan_core_dirs(x)
+            return self._scan_core_dirs(x, channel_last)
+        if channel_last:
+            x = x.permute(0, 3, 1, 2)
         B, D, H, W = x.shape
         L, K, N, R = H * W, 4, self.d_state, self.dt_rank
         xs = cross_scan(x)                                                        # (B, 4, D, L)
@@ -213,12 +222,14 @@ class SS2D(nn.Module):
         else:
             halves = None
             xh, z = torch.split(xz, D, dim=-1)     # views; split's backward is one cat instead of two zero-fills + add
-        xc = dwconv3x3_silu(xh, self.conv2d.weight, self.conv2d.bias, channel_last_in=True, holder=halves)
+        # the convolution output stays channel-last (no transposing tile in the convolution; the scatter reads either layout)
+        cl = bool(fused_gate and xz.is_cuda and self.fused_directions and D % 4 == 0 and not os.environ.get("SS2D_NO_CL_CONV"))
+        xc = dwconv3x3_silu(xh, self.conv2d.weight, self.conv2d.bias, channel_last_in=True, holder=halves, channel_last_out=cl)
         fold = (residual is not None and fused_gate and xz.is_cuda and self.dropout is None and self.out_proj.bias is None
                 and not os.environ.get("SS2D_NO_LINEAR_RES"))
         if fused_gate:
             # out_norm, SiLU(z) and the product in one kernel (:452 + :561)
-            y = outnorm_gate(self._scan_core(xc), z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, holder=halves,
+            y = outnorm_gate(self._scan_core(xc, cl), z, self.out_norm.weight, self.out_norm.bias, self.out_norm.eps, holder=halves,
                              scale=drop_scale if fold else None)
         else:
             y = self.forward_core(xc)

@@ -172,6 +172,73 @@ class _DwConvSiLU(torch.autograd.Function):
         return dx.to(in_dtype), dw.to(w_dtype), None if db is None else db.to(b_dtype), None, None
 
 
+def _pixel_pitch(t, D):
+    """Pitch (elements between pixels) of a (B, H, W, D) tensor whose pixels lie at a constant distance with the D channels
+    contiguous -- a dense tensor or a channel slice of a wider one (the x half of xz) -- else None."""
+    B, H, W, _ = t.shape
+    ld = t.stride(2)
+    if t.stride(3) == 1 and t.stride(1) == W * ld and t.stride(0) == H * W * ld and ld >= D and ld % 4 == 0 \
+            and t.data_ptr() % (4 * t.element_size()) == 0:
+        return ld
+    return None
+
+
+class _DwConvSiLUCL(torch.autograd.Function):
+    """SiLU(depthwise conv3x3(x) + bias) with channel-last tensors on both sides (csrc/ss2d_dwconv_cl.hip): x (B, H, W, D),
+    possibly a channel slice of a wider tensor, -> y (B, H, W, D); the backward takes a channel-last dy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, holder=None):
+        ctx.holder = holder
+        _need_gpu(x, "dwconv3x3_silu")
+        in_dtype = x.dtype
+        io, code = _io(x)
+        B, H, W, D = x.shape
+        xf = x.to(io)
+        ldx = _pixel_pitch(xf, D)
+        if ldx is None:
+            xf = xf.contiguous()
+            ldx = D
+        if tuple(weight.shape) != (D, 1, 3, 3):
+            raise ValueError(f"dwconv3x3_silu: weight must be ({D}, 1, 3, 3), got {tuple(weight.shape)}")
+        wf = weight.float().contiguous()
+        bf = None if bias is None else bias.float().contiguous()
+        if wf.data_ptr() % 16:           # the kernels fetch a lane's 36 taps / 4 biases as 16-byte pieces
+            wf = wf.clone()
+        if bf is not None and bf.data_ptr() % 16:
+            bf = bf.clone()
+        y = torch.empty((B, H, W, D), device=x.device, dtype=io)
+        with _lib.on_device(x.device):
+            rc = _lib.load().ss2d_dwconv3x3_silu_cl_fwd(code, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(y),
+                                                        B, D, H, W, ldx, D, _stream())
+        _lib.check(rc, "ss2d_dwconv3x3_silu_cl_fwd")
+        ctx.save_for_backward(xf, wf, bf)
+        ctx.meta = (B, D, H, W, ldx, in_dtype, weight.dtype, None if bias is None else bias.dtype, code)
+        return y.to(in_dtype)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xf, wf, bf = ctx.saved_tensors
+        B, D, H, W, ldx, in_dtype, w_dtype, b_dtype, code = ctx.meta
+        g = dy.to(xf.dtype)
+        lddy = _pixel_pitch(g, D)
+        if lddy is None:
+            g = g.contiguous()
+            lddy = D
+        buf = ctx.holder.buf if ctx.holder is not None else None
+        if buf is not None and buf.dtype == xf.dtype and tuple(buf.shape) == (B, H, W, 2 * D) and buf.is_contiguous():
+            dx, lddx = buf[..., :D], 2 * D          # first half of the shared d(xz) buffer (GradHalves)
+        else:
+            dx, lddx = torch.empty((B, H, W, D), device=g.device, dtype=xf.dtype), D
+        dw, db = _lib.zeros_group(g.device, tuple(wf.shape), None if bf is None else tuple(bf.shape))
+        with _lib.on_device(g.device):
+            rc = _lib.load().ss2d_dwconv3x3_silu_cl_bwd(code, _lib.ptr(xf), _lib.ptr(wf), _lib.ptr(bf), _lib.ptr(g),
+                                                        _lib.ptr(dx), _lib.ptr(dw), _lib.ptr(db), B, D, H, W, ldx, lddy, lddx,
+                                                        _stream())
+        _lib.check(rc, "ss2d_dwconv3x3_silu_cl_bwd")
+        return dx.to(in_dtype), dw.to(w_dtype), None if db is None else db.to(b_dtype), None
+
+
 def cross_scan(x: torch.Tensor) -> torch.Tensor:
     """(B, D, H, W) -> (B, 4, D, H*W): row-major, column-major and their reversals (mamba_sys.py:403-404)."""
     return _CrossScan.apply(x)
@@ -182,9 +249,16 @@ def cross_merge(ys: torch.Tensor, H: int, W: int, channel_last: bool = True) -> 
     return _CrossMerge.apply(ys, H, W, channel_last)
 
 
-def dwconv3x3_silu(x: torch.Tensor, weight: torch.Tensor, bias, channel_last_in: bool = True, holder=None) -> torch.Tensor:
-    """SiLU(depthwise conv3x3(x) + bias) -> (B, D, H, W).  x is (B, H, W, D) (channel_last_in; may be a
-    channel slice of a wider tensor) or (B, D, H, W).  mamba_sys.py:299-308, :558-559.  `holder`: see GradHalves."""
+def dwconv3x3_silu(x: torch.Tensor, weight: torch.Tensor, bias, channel_last_in: bool = True, holder=None,
+                   channel_last_out: bool = False) -> torch.Tensor:
+    """SiLU(depthwise conv3x3(x) + bias) -> (B, D, H, W), or (B, H, W, D) with `channel_last_out`.  x is (B, H, W, D)
+    (channel_last_in; may be a channel slice of a wider tensor) or (B, D, H, W).  mamba_sys.py:299-308, :558-559.
+    `holder`: see GradHalves.  Channel-last on both sides with D % 4 == 0 runs the kernels of csrc/ss2d_dwconv_cl.hip
+    (nothing is transposed); every other combination the tile kernels of csrc/ss2d_dwconv.hip."""
+    if channel_last_out:
+        if channel_last_in and x.shape[-1] % 4 == 0 and x.is_cuda:
+            return _DwConvSiLUCL.apply(x, weight, bias, holder)
+        return _DwConvSiLU.apply(x, weight, bias, channel_last_in, holder).permute(0, 2, 3, 1)
     return _DwConvSiLU.apply(x, weight, bias, channel_last_in, holder)
 
 
@@ -869,18 +943,21 @@ class _DirsScatter2(torch.autograd.Function):
     H*W positions, `pitch` apart, the pad zero."""
 
     @staticmethod
-    def forward(ctx, x, holder=None, pitch=None):
+    def forward(ctx, x, holder=None, pitch=None, channel_last=False):
         _need_gpu(x, "dirs_scatter2")
         ctx.holder = holder
-        B, D, H, W = x.shape
+        if channel_last:
+            B, H, W, D = x.shape
+        else:
+            B, D, H, W = x.shape
         pitch = H * W if pitch is None else int(pitch)
         io, code = _io(x)
         xf = x.to(io).contiguous()
         xs = (torch.empty if pitch == H * W else torch.zeros)((B, 2, D, pitch), device=x.device, dtype=io)
         with _lib.on_device(x.device):
-            rc = _lib.load().ss2d_dirs_scatter_ld(code, 2, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, 0, pitch, _stream())
+            rc = _lib.load().ss2d_dirs_scatter_ld(code, 2, _lib.ptr(xf), _lib.ptr(xs), B, D, H, W, int(channel_last), pitch, _stream())
         _lib.check(rc, "ss2d_dirs_scatter_ld")
-        ctx.shape, ctx.in_dtype, ctx.pitch = (B, D, H, W), x.dtype, pitch
+        ctx.shape, ctx.in_dtype, ctx.pitch, ctx.cl = (B, D, H, W), x.dtype, pitch, bool(channel_last)
         return xs.to(x.dtype)
 
     @staticmethod
@@ -888,33 +965,36 @@ class _DirsScatter2(torch.autograd.Function):
         B, D, H, W = ctx.shape
         pitch = ctx.pitch
         io, code = _io(dxs)
+        cl = ctx.cl
         g = dxs.to(io).contiguous()
-        dx = torch.empty((B, D, H, W), device=g.device, dtype=io)
+        dx = torch.empty((B, H, W, D) if cl else (B, D, H, W), device=g.device, dtype=io)
         du = None
         if ctx.holder is not None:
             du, ctx.holder.du = ctx.holder.du, None
         with _lib.on_device(g.device):
             if du is not None and du.dtype == io and tuple(du.shape) == (B, 4 * D, pitch) and du.is_contiguous():
-                rc = _lib.load().ss2d_dirs_gather6_ld(code, _lib.ptr(du), _lib.ptr(g), _lib.ptr(dx), B, D, H, W, pitch, _stream())
+                gather6 = _lib.load().ss2d_dirs_gather6_cl_ld if cl else _lib.load().ss2d_dirs_gather6_ld
+                rc = gather6(code, _lib.ptr(du), _lib.ptr(g), _lib.ptr(dx), B, D, H, W, pitch, _stream())
                 du = None
             else:
-                rc = _lib.load().ss2d_dirs_gather_ld(code, 2, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, 0, pitch, _stream())
+                rc = _lib.load().ss2d_dirs_gather_ld(code, 2, _lib.ptr(g), _lib.ptr(dx), B, D, H, W, int(cl), pitch, _stream())
         _lib.check(rc, "ss2d_dirs_gather_ld")
         if du is not None:      # a du this node could not fold in (dtype / shape): gather it the plain way and add
             dx2 = torch.empty_like(dx)
             du = du.to(io).contiguous()
             with _lib.on_device(g.device):
-                rc = _lib.load().ss2d_dirs_gather_ld(code, 1, _lib.ptr(du), _lib.ptr(dx2), B, D, H, W, 0, du.shape[-1], _stream())
+                rc = _lib.load().ss2d_dirs_gather_ld(code, 1, _lib.ptr(du), _lib.ptr(dx2), B, D, H, W, int(cl), du.shape[-1], _stream())
             _lib.check(rc, "ss2d_dirs_gather_ld")
             dx = dx + dx2
-        return dx.to(ctx.in_dtype), None, None
+        return dx.to(ctx.in_dtype), None, None, None
 
 
-def dirs_scatter2(x: torch.Tensor, holder=None, pitch=None) -> torch.Tensor:
-    """(B, D, H, W) -> (B, 2, D, H*W): x flattened row-major and column-major -- the two orientations of CrossScan
-    (mamba_sys.py:403); the two reversed directions (:404) are read from the same copies by the scan itself.  With
-    `pitch` > H*W the rows are that far apart and zero behind their H*W positions (see SS2D._scan_core_dirs)."""
-    return _DirsScatter2.apply(x, holder, pitch)
+def dirs_scatter2(x: torch.Tensor, holder=None, pitch=None, channel_last: bool = False) -> torch.Tensor:
+    """(B, D, H, W) -- or (B, H, W, D) with `channel_last` -- -> (B, 2, D, H*W): x flattened row-major and column-major -- the
+    two orientations of CrossScan (mamba_sys.py:403); the two reversed directions (:404) are read from the same copies by
+    the scan itself.  With `pitch` > H*W the rows are that far apart and zero behind their H*W positions (see
+    SS2D._scan_core_dirs)."""
+    return _DirsScatter2.apply(x, holder, pitch, channel_last)
 
 
 class _DtProj(torch.autograd.Function):

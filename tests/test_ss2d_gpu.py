@@ -96,6 +96,40 @@ def test_dwconv_silu_fwd_bwd(B, D, H, W, cl, reps, monkeypatch):
     assert rel_max(wd.grad.cpu(), wr.grad) < 1e-5 and rel_max(bd.grad.cpu(), br.grad) < 1e-5
 
 
+@pytest.mark.parametrize("B,D,H,W", [(2, 8, 4, 6), (1, 40, 9, 33), (2, 64, 14, 14), (1, 192, 56, 56), (24, 40, 7, 7),
+                                     (3, 36, 17, 16), (2, 24, 20, 40), (2, 100, 31, 61)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("reps", [None, "3"])
+def test_dwconv_silu_channel_last_both_sides(B, D, H, W, dtype, reps, monkeypatch):
+    """The channel-last convolution (csrc/ss2d_dwconv_cl.hip: float4 of channels per lane, no transposing tile) against
+    the fp64 oracle: output, dx (written into the x half of a wide tensor, the other half untouched), dw, dbias; ragged
+    channel tiles (D % 32 != 0), ragged column tiles and row bands, several units per workgroup (reps)."""
+    from mamba_unet_amd import dwconv3x3_silu
+    from mamba_unet_amd.ss2d_ops import _DwConvSiLUCL
+    if reps is not None:
+        monkeypatch.setenv("SS2D_DWCONV_REPS", reps)
+    from oracle.ss2d_ref import dwconv3x3_silu_ref
+    g = torch.Generator().manual_seed(D + W)
+    wide = torch.randn(B, H, W, 2 * D, generator=g).to(dtype)
+    w = torch.randn(D, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(D, generator=g) * 0.1
+    gy = torch.randn(B, H, W, D, generator=g).to(dtype)
+    xr = wide[..., :D].permute(0, 3, 1, 2).double().requires_grad_(True)
+    wr, br = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = dwconv3x3_silu_ref(xr, wr, br)
+    (yr * gy.double().permute(0, 3, 1, 2)).sum().backward()
+    wide_d = wide.cuda().requires_grad_(True)
+    wd, bd = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    yd = dwconv3x3_silu(wide_d[..., :D], wd, bd, channel_last_in=True, channel_last_out=True)
+    assert yd.shape == (B, H, W, D) and yd.dtype == dtype and yd.grad_fn.name().startswith(_DwConvSiLUCL.__name__)
+    (yd * gy.cuda()).sum().backward()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_max(yd.detach().float().cpu().permute(0, 3, 1, 2), yr.detach()) < tol
+    assert rel_max(wide_d.grad[..., :D].float().cpu(), xr.grad.permute(0, 2, 3, 1)) < tol
+    assert float(wide_d.grad[..., D:].abs().max()) == 0.0
+    assert rel_max(wd.grad.cpu(), wr.grad) < tol and rel_max(bd.grad.cpu(), br.grad) < tol
+
+
 @pytest.mark.parametrize("name", ["ss2d_2x8x5x7_s0.npz", "ss2d_1x16x8x8_s1.npz", "ss2d_2x96x14x14_s0.npz"])
 def test_ss2d_module_matches_reference_golden(name):
     """Outputs and ALL gradients of the reference's own SS2D (tests/golden, made by make_golden.py)."""
