@@ -73,12 +73,18 @@ def test_ddp_wrapped_mambaunet_supervised_steps_equal_unwrapped(world_of_one, bf
         # bf16: two EAGER runs already differ by ~2e-5 (tests/test_configs_gpu.py::test_graphed_supervised_step_matches_eager)
         assert abs(l1 - l2) <= (1e-3 if bf16 else 1e-6) * abs(l1), (it, l1, l2)
     # every parameter took part in every step: gradients present, finite, living in DDP's buckets (views), and equal
-    worst = 0.0
+    # bf16: the float atomics of the bf16 weight-gradient kernels make two EAGER runs of the bare network differ too, and
+    # three steps amplify it -- measured over four trials of bare against bare: worst single parameter (an x_proj weight)
+    # 2.4e-2 ... 6.1e-2, all gradients together 2.5e-3, the same figures with and without the wrapper.  The gates are ~5x / 4x
+    # those; the fp32 gate is the sharp one.
+    worst, num, den2 = 0.0, 0.0, 0.0
     for (k, p), q in zip(bare.named_parameters(), twin.parameters()):
         assert q.grad is not None and torch.isfinite(q.grad).all(), k
-        den = float(p.grad.norm())
-        worst = max(worst, float((p.grad - q.grad).norm()) / (den if den > 0 else 1.0))
-    assert worst < (5e-2 if bf16 else 1e-4), worst
+        d, den = float((p.grad - q.grad).norm()), float(p.grad.norm())
+        worst = max(worst, d / (den if den > 0 else 1.0))
+        num, den2 = num + d * d, den2 + den * den
+    assert worst < (3e-1 if bf16 else 1e-4), worst
+    assert (num / den2) ** 0.5 < (1e-2 if bf16 else 1e-4), (num / den2) ** 0.5
     wmax = max(float((p.detach() - q.detach()).abs().max()) for p, q in zip(bare.parameters(), twin.parameters()))
     assert wmax < (1e-3 if bf16 else 1e-6), wmax
 
