@@ -97,7 +97,10 @@ def test_dwconv_silu_fwd_bwd(B, D, H, W, cl, reps, monkeypatch):
 
 
 @pytest.mark.parametrize("B,D,H,W", [(2, 8, 4, 6), (1, 40, 9, 33), (2, 64, 14, 14), (1, 192, 56, 56), (24, 40, 7, 7),
-                                     (3, 36, 17, 16), (2, 24, 20, 40), (2, 100, 31, 61)])
+                                     (3, 36, 17, 16), (2, 24, 20, 40), (2, 100, 31, 61),
+                                     # degenerate planes, the narrow / wide switch (W = 14 | 15), the 30-column tile edge
+                                     (1, 4, 1, 1), (2, 8, 1, 5), (1, 4, 3, 2), (1, 12, 2, 17), (1, 68, 9, 15), (1, 8, 5, 14),
+                                     (1, 8, 16, 30), (1, 8, 8, 31), (1, 8, 9, 60)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("reps", [None, "3"])
 def test_dwconv_silu_channel_last_both_sides(B, D, H, W, dtype, reps, monkeypatch):
