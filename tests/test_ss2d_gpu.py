@@ -154,6 +154,51 @@ def test_ss2d_module_matches_reference_golden(name):
         assert rel_l2(p.grad.cpu(), g["grad." + k]) < 1e-5, (k, rel_l2(p.grad.cpu(), g["grad." + k]))
 
 
+@pytest.mark.parametrize("switch", ["SS2D_NO_GATHER6", "SS2D_NO_CL_CONV", "SS2D_NO_BLOCK_PARAMS", "SS2D_NO_PACKED_DXDBL"])
+def test_ss2d_golden_with_one_fusion_switched_off(switch, monkeypatch):
+    """The routes behind the A/B switches stay correct (README): the channel-last convolution output with the plain gathers
+    (no 6-slot gather), the (B, D, H, W) convolution, per-parameter transforms, the separate dB / dC packing pass -- each
+    against the reference's SS2D fixture, output and every gradient."""
+    from mamba_unet_amd import SS2D
+    from mamba_unet_amd.selective_scan_interface import ScanCoreFn
+    monkeypatch.setenv(switch, "1")
+    if switch == "SS2D_NO_PACKED_DXDBL":
+        monkeypatch.setattr(ScanCoreFn, "PACKED_DXDBL", False)      # class-wide switch, read from the environment at import
+    g = np.load(os.path.join(GOLDEN, "ss2d_2x96x14x14_s0.npz"))
+    m = SS2D(d_model=g["x"].shape[-1])
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    m = m.cuda()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = m(x)
+    assert rel_max(y.detach().cpu(), g["y"]) < 5e-6
+    (y * torch.from_numpy(g["g"]).cuda()).sum().backward()
+    assert rel_l2(x.grad.cpu(), g["dx"]) < 5e-6
+    for k, p in m.named_parameters():
+        assert rel_l2(p.grad.cpu(), g["grad." + k]) < 1e-5, (k, rel_l2(p.grad.cpu(), g["grad." + k]))
+
+
+def test_ss2d_bf16_autocast_with_fp32_scan_io_matches_the_fixture():
+    """bf16 autocast with SS2D.bf16_scan_io off (the reference's casts around the scan, mamba_sys.py:423-426): the channel-last
+    convolution output goes back to (B, D, H, W) for the literal composition.  Output and dx against the fp32 fixture at
+    the bf16 gate of north_star (1e-2, relative L2)."""
+    from mamba_unet_amd import SS2D
+    g = np.load(os.path.join(GOLDEN, "ss2d_2x96x14x14_s0.npz"))
+    m = SS2D(d_model=g["x"].shape[-1])
+    m.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("sd.")})
+    m = m.cuda()
+    old = SS2D.bf16_scan_io
+    try:
+        SS2D.bf16_scan_io = False
+        x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = m(x)
+        (y.float() * torch.from_numpy(g["g"]).cuda()).sum().backward()
+    finally:
+        SS2D.bf16_scan_io = old
+    assert rel_l2(y.detach().float().cpu(), g["y"]) < 1e-2
+    assert rel_l2(x.grad.float().cpu(), g["dx"]) < 1e-2
+
+
 def test_vssm_small_logits_match_reference_golden():
     from mamba_unet_amd import VSSM
     g = np.load(os.path.join(GOLDEN, "vssm_small.npz"))
