@@ -43,6 +43,33 @@ def test_vssm_small_gradients_match_reference_autograd():
     assert {k for k, _ in m.named_parameters()} == {k[5:] for k in g.files if k.startswith("grad.")}
 
 
+@pytest.mark.parametrize("switch", ["SS2D_NO_LINEAR_RES", "SS2D_NO_LN_SKIP", "SS2D_NO_FUSE_DELTA", "SS2D_NO_CL_CONV", "SS2D_NO_GATHER6"])
+def test_vssm_small_gradients_with_one_fusion_switched_off(switch, monkeypatch):
+    """The block-level routes behind the A/B switches (README) against the same reference autograd fixture: residual add
+    and residual gradient as separate torch ops, delta materialised by the dt_proj kernel, the (B, D, H, W) convolution,
+    the plain gathers.  (Class-wide switches are read from the environment at import: set on the class here.)"""
+    from mamba_unet_amd import VSSM
+    from mamba_unet_amd.selective_scan_interface import ScanCoreFn
+    monkeypatch.setenv(switch, "1")
+    if switch == "SS2D_NO_FUSE_DELTA":
+        monkeypatch.setattr(ScanCoreFn, "FUSE_DELTA", False)
+    if switch == "SS2D_NO_LN_SKIP":
+        from mamba_unet_amd import ss2d_ops
+        monkeypatch.setattr(ss2d_ops, "_NO_LN_SKIP", True)
+    sd = np.load(os.path.join(GOLDEN, "vssm_small.npz"))
+    g = np.load(os.path.join(GOLDEN, "vssm_small_grads.npz"))
+    m = VSSM(patch_size=4, in_chans=3, num_classes=4, depths=[1, 1, 1, 1], dims=[16, 32, 64, 128], drop_path_rate=0.2)
+    m.load_state_dict({k[3:]: torch.from_numpy(sd[k]) for k in sd.files if k.startswith("sd.")})
+    m = m.cuda().eval()
+    x = torch.from_numpy(g["x"]).cuda().requires_grad_(True)
+    y = m(x)
+    assert rel_l2(y.detach().cpu(), g["logits"]) < 1e-5
+    (y * torch.from_numpy(g["g"]).cuda()).sum().backward()
+    assert rel_l2(x.grad.cpu(), g["dx"]) < 1e-5
+    worst = max((rel_l2(p.grad.cpu(), g["grad." + k]), k) for k, p in m.named_parameters())
+    assert worst[0] < 3e-5, worst
+
+
 def test_config2_batch24_bf16_training_step():
     """BASELINE configs[2]: MambaUNet full training step, batch 24, 224x224, 4 classes, bf16."""
     from mamba_unet_amd import SS2D, MambaUnet
